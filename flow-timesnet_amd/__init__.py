@@ -1,0 +1,20 @@
+"""flow-timesnet_amd — MI355X-native (gfx950) TimesBlock forward path for
+Flow-TimesNet, behind the reference's own PyTorch-module API.
+
+Sub-modules
+-----------
+``synth``            seeded synthetic weights / inputs (numpy only)
+``lib``              ctypes binding of ``csrc/libflowtimes_hip.so`` (the C-ABI in ``include/flowtimes.h``)
+``pack``             host-side weight folding/packing for the HIP kernels
+``models.timesnet``  drop-in mirrors of the reference modules
+``dist``             batch-sharded multi-GPU forward (RCCL via torch.distributed)
+"""
+from . import synth  # noqa: F401
+
+
+def __getattr__(name):  # lazy: keeps `import flow_timesnet_amd.synth` torch-free
+    import importlib
+
+    if name in ("lib", "pack", "models", "dist", "grouping"):
+        return importlib.import_module(f"{__name__}.{name}")
+    raise AttributeError(name)
