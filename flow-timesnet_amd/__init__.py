@@ -15,6 +15,6 @@ from . import synth  # noqa: F401
 def __getattr__(name):  # lazy: keeps `import flow_timesnet_amd.synth` torch-free
     import importlib
 
-    if name in ("lib", "pack", "models", "dist", "grouping"):
+    if name in ("lib", "pack", "models", "dist", "grouping", "runtime"):
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

@@ -1,0 +1,126 @@
+// Shared host/device helpers for libflowtimes_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/flowtimes.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+void ftn_set_error(const char* fmt, ...);
+
+#define FTN_CHECK_ARG(cond, ...)        \
+  do {                                  \
+    if (!(cond)) {                      \
+      ftn_set_error(__VA_ARGS__);       \
+      return -1;                        \
+    }                                   \
+  } while (0)
+
+#define FTN_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e_ = hipGetLastError();                       \
+    if (e_ != hipSuccess) {                                  \
+      ftn_set_error("%s:%d: %s", __FILE__, __LINE__,        \
+                    hipGetErrorString(e_));                  \
+      return (int)e_;                                        \
+    }                                                        \
+  } while (0)
+
+static inline int ftn_pad16(int v) { return (v + 15) & ~15; }
+static inline int ftn_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- conv tiling: one rule shared by the device finalize kernel and the host --
+#define FTN_TILE_PX 256   // max pixels of one conv tile (4 waves x 4 units x 16 px)
+#define FTN_TILE_W 64
+#define FTN_TILE_H 64
+
+__host__ __device__ inline void ftn_tile_geometry(int cycles, int period, int* tw, int* th,
+                                                  int* ntx, int* nty) {
+  int nx = (period + FTN_TILE_W - 1) / FTN_TILE_W;
+  int w = (period + nx - 1) / nx;
+  int hmax = FTN_TILE_PX / w;
+  if (hmax > FTN_TILE_H) hmax = FTN_TILE_H;
+  if (hmax < 1) hmax = 1;
+  int ny = (cycles + hmax - 1) / hmax;
+  int h = (cycles + ny - 1) / ny;
+  *tw = w; *th = h; *ntx = nx; *nty = ny;
+}
+
+// Groups distinct valid periods ascending, fills mapping/pad/cycles/offsets/tiles.
+// `periods[K]` are the selector's kept candidates (score order, duplicates allowed).
+// Mirrors PeriodGrouper.group with env flags unset (reference :513-557).
+__host__ __device__ inline void ftn_build_groups(const int* periods, int K, int L, int min_period,
+                                                 int max_period, FtnDesc* d) {
+  int G = 0;
+  for (int j = 0; j < FTN_KMAX; ++j) d->sel_group[j] = -1;
+  for (int j = 0; j < K; ++j) {
+    int p = periods[j];
+    if (p <= 0 || p < min_period || p > max_period) continue;
+    int pad = (p - (L % p)) % p;
+    int cyc = (L + pad) / p;
+    if (cyc < 2) continue;
+    int g = 0;
+    while (g < G && d->g_period[g] != p) ++g;
+    if (g == G) { d->g_period[G] = p; ++G; }
+  }
+  // ascending insertion sort of the distinct periods
+  for (int a = 1; a < G; ++a) {
+    int v = d->g_period[a], b = a - 1;
+    while (b >= 0 && d->g_period[b] > v) { d->g_period[b + 1] = d->g_period[b]; --b; }
+    d->g_period[b + 1] = v;
+  }
+  int px = 0, tiles = 0;
+  for (int g = 0; g < G; ++g) {
+    int p = d->g_period[g];
+    int pad = (p - (L % p)) % p;
+    d->g_pad[g] = pad;
+    d->g_cycles[g] = (L + pad) / p;
+    d->g_px_off[g] = px;
+    px += L + pad;
+    ftn_tile_geometry(d->g_cycles[g], p, &d->g_tw[g], &d->g_th[g], &d->g_ntx[g], &d->g_nty[g]);
+    d->g_tile_off[g] = tiles;
+    tiles += d->g_ntx[g] * d->g_nty[g];
+  }
+  d->g_px_off[G] = px;
+  d->g_tile_off[G] = tiles;
+  for (int g = G; g < FTN_KMAX; ++g) {
+    d->g_period[g] = 0; d->g_pad[g] = 0; d->g_cycles[g] = 0;
+    d->g_tw[g] = 0; d->g_th[g] = 0; d->g_ntx[g] = 0; d->g_nty[g] = 0;
+    if (g > G) { d->g_px_off[g] = px; d->g_tile_off[g] = tiles; }
+  }
+  for (int j = 0; j < K; ++j) {
+    int p = periods[j];
+    if (p <= 0 || p < min_period || p > max_period) continue;
+    int pad = (p - (L % p)) % p;
+    if ((L + pad) / p < 2) continue;
+    for (int g = 0; g < G; ++g)
+      if (d->g_period[g] == p) d->sel_group[j] = g;
+  }
+  d->n_groups = G;
+  d->total_px = px;
+  d->tiles_per_row = tiles;
+}
+
+#ifdef __HIPCC__
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15];
+// result register r of lane l is D[i=4*(l>>4)+r][j=l&15]  (cdna_hip_programming.md §3).
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+  if (ACT == 1) return v > 0.0f ? v : 0.0f;
+  return gelu_erf(v);
+}
+template <int ACT>
+__device__ __forceinline__ f4 act4(f4 v) {
+  f4 r;
+  r.x = act_fn<ACT>(v.x); r.y = act_fn<ACT>(v.y); r.z = act_fn<ACT>(v.z); r.w = act_fn<ACT>(v.w);
+  return r;
+}
+#endif

