@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — TimesBlock-forward series/sec on MI355X (BASELINE.json metric).
+
+One "step" = one TimesBlock forward (period selector + all period groups'
+inception convs + aggregation) over one synthetic batch already resident in HBM.
+Workload (N=1): B=256, L=336, N=512 series (d_model=64 embedded channels,
+d_ff=256, kernels 3/5/7, bottleneck ratio 4, k_periods=5), fp32.  ``series/sec``
+= B*N / t (TimesBlock never sees N: SURVEY finding 2).  With --gpus G every rank
+owns a B=256 shard of a G*256 batch (weak scaling): one [F]-float exchange per
+step for the shared periods, then an all-gather of the outputs (RCCL).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as ge  # noqa: E402
+
+STAGES = ["A_pw_in(k_pw)", "B_conv1(k_conv)", "C_chain(k_mlp)", "D_conv2(k_conv)", "E_pw_out(k_pw)", "F_combine"]
+FP32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def stage_macs(C, F, ks, ratio, pack):
+    """Executed MAC/pixel of each stage (folded weights, unpadded channels)."""
+    from math import ceil
+    nk = len(ks)
+    mid = max(1, int(ceil(min(C, F) / ratio)))
+    taps = sum(kh * kw for kh, kw in ks)
+    return [C * nk * mid, mid * mid * taps, nk * mid * F + C * F + F * nk * mid + F * C, mid * mid * taps,
+            nk * mid * C, 0]
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seq-len", type=int, default=336)
+    ap.add_argument("--series", type=int, default=512)
+    ap.add_argument("--d-model", type=int, default=64)
+    ap.add_argument("--k-periods", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    pkg = ge.load_package()
+    lib = pkg.lib.load()
+    T = pkg.models.timesnet
+    B, L, C, K, NS = args.batch, args.seq_len, args.d_model, args.k_periods, args.series
+    F = 4 * C
+    ks = [(3, 3), (5, 5), (7, 7)]
+    ratio = 4.0
+    params = pkg.synth.make_inception_params(C, F, ks, ratio, seed=0)
+    blk = T.TimesBlock(C, ks, 0.0, "gelu", d_ff=F, bottleneck_ratio=ratio)
+    blk.inception.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    blk.period_selector = T.FFTPeriodSelector(K, L)
+    blk = blk.eval().to(dev)
+    x_host = pkg.synth.make_input(B, L, C, seed=rank)
+    x = torch.from_numpy(x_host).to(dev)
+
+    if world > 1:
+        import torch.distributed as dist
+        runner = pkg.dist.ShardedTimesBlock(blk)
+        step = lambda: runner(x, gather=True)
+        barrier = lambda: dist.barrier()
+    else:
+        step = lambda: blk(x)
+        barrier = lambda: None
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            y = step()
+        torch.cuda.synchronize()
+        barrier()
+        pkg.lib.check(lib.ftn_stage_timing(1), "ftn_stage_timing")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = step()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+    assert blk._last_backend == "hip"
+    elapsed = t1 - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_sum = (ctypes.c_float * 6)()
+    ncalls = ctypes.c_int(0)
+    pkg.lib.check(lib.ftn_stage_times(ms_sum, 6, ctypes.byref(ncalls)), "ftn_stage_times")
+    lib.ftn_stage_timing(0)
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * B * NS / (elapsed / args.steps)
+
+    if rank == 0:
+        d = blk.period_selector._pending.host() if blk.period_selector._pending is not None else None
+        periods = blk.period_selector.last_selected_periods.tolist()
+        G = int(blk._last_group_count)
+        # pixels one launch processes: B * sum_g (L + pad_g)
+        pads = [(-L) % p for p in sorted(set(periods))]
+        px = B * sum(L + pd for pd in pads)
+        stage_ms = [ms_sum[i] / max(1, ncalls.value) for i in range(6)]
+        macs = stage_macs(C, F, ks, ratio, pkg.pack)
+        dom = int(np.argmax(stage_ms))
+        flops_exec = 2.0 * macs[dom] * px
+        achieved = flops_exec / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
+        nominal = 2.0 * pkg.pack.macs_per_pixel(C, F, ks, ratio) * px
+        executed = 2.0 * pkg.pack.macs_per_pixel(C, F, ks, ratio, folded=True) * px
+        conv_ms = sum(stage_ms)
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_latest.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get(STAGES[dom])
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "TimesBlock-forward series/sec (B=256 L=336 N=512)",
+            "value": value, "unit": "series/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"timesblock_fwd B={B}/gpu L={L} N={NS} d_model={C} d_ff={F} kernels=3/5/7 "
+                                   f"ratio=4 k_periods={K} fp32 (BASELINE configs[2] shape, fp32 compute)",
+                       "windows_per_s": world * B / (elapsed / args.steps), "periods": periods, "groups": G,
+                       "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
+            "roofline": {"bound": "mfma", "kernel": STAGES[dom], "achieved": achieved, "peak": FP32_MFMA_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": traffic,
+                         "flops_per_launch": flops_exec, "avg_launch_ms": stage_ms[dom],
+                         "stage_ms": dict(zip(STAGES, [round(v, 4) for v in stage_ms])),
+                         "conv_path_ms": conv_ms,
+                         "block_executed_tflops": executed / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                         "block_nominal_tflops": nominal / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, params, ks, x_host, K, L, NS)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, params, ks, x_host, K, L, NS):
+    """The CPU oracle (stock torch CPU ops composed the reference's way) timed on
+    this box's host cores on the same batch; bounded to ~20 s."""
+    from oracle import timesblock_oracle as orc
+    P = {k: torch.from_numpy(v) for k, v in params.items()}
+    xt = torch.from_numpy(x_host)
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        orc.timesblock_forward(xt[:32], P, ks, "gelu", K, L)            # warm-up
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 5 and time.perf_counter() - t_start < 20.0:
+            t0 = time.perf_counter()
+            orc.timesblock_forward(xt, P, ks, "gelu", K, L)
+            times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    return {"value": xt.shape[0] * NS / t, "unit": "series/s", "cores": threads, "kind": "port",
+            "ms_per_step": t * 1e3,
+            "sample": f"{len(times)} forwards of the full batch B={xt.shape[0]} (median), torch {torch.__version__} "
+                      f"CPU ops, {threads} threads"}
+
+
+if __name__ == "__main__":
+    main()

@@ -474,6 +474,54 @@ __global__ void k_combine(const float* __restrict__ x, float* __restrict__ y, co
   }
 }
 
+// ---------------------------------------------------------------- stage timing
+// Optional hipEvent brackets around the stages of ftn_timesblock_forward, kept in
+// a pool so that nothing synchronises while a timed region runs; read back (with
+// one synchronise) by ftn_stage_times.  Used by bench.py for the roofline figures.
+#define FTN_NSTAGE 6
+#define FTN_PROF_CALLS 512
+static struct StageProf {
+  bool on = false;
+  bool created = false;
+  int calls = 0;
+  hipEvent_t ev[FTN_PROF_CALLS][FTN_NSTAGE + 1];
+} g_prof;
+
+static void prof_mark(int stage, hipStream_t st) {
+  if (g_prof.on && g_prof.calls < FTN_PROF_CALLS) (void)hipEventRecord(g_prof.ev[g_prof.calls][stage], st);
+}
+
+extern "C" int ftn_stage_timing(int enable) {
+  if (enable && !g_prof.created) {
+    for (int c = 0; c < FTN_PROF_CALLS; ++c)
+      for (int s = 0; s <= FTN_NSTAGE; ++s) {
+        hipError_t e = hipEventCreate(&g_prof.ev[c][s]);
+        if (e != hipSuccess) { ftn_set_error("hipEventCreate: %s", hipGetErrorString(e)); return (int)e; }
+      }
+    g_prof.created = true;
+  }
+  g_prof.on = enable != 0;
+  g_prof.calls = 0;
+  return 0;
+}
+
+extern "C" int ftn_stage_times(float* ms_sum, int nstage, int* ncalls) {
+  FTN_CHECK_ARG(ms_sum && ncalls && nstage == FTN_NSTAGE, "ftn_stage_times: expects %d stages", FTN_NSTAGE);
+  for (int s = 0; s < FTN_NSTAGE; ++s) ms_sum[s] = 0.f;
+  *ncalls = g_prof.calls;
+  for (int c = 0; c < g_prof.calls; ++c) {
+    hipError_t e = hipEventSynchronize(g_prof.ev[c][FTN_NSTAGE]);
+    if (e != hipSuccess) { ftn_set_error("hipEventSynchronize: %s", hipGetErrorString(e)); return (int)e; }
+    for (int s = 0; s < FTN_NSTAGE; ++s) {
+      float ms = 0.f;
+      e = hipEventElapsedTime(&ms, g_prof.ev[c][s], g_prof.ev[c][s + 1]);
+      if (e != hipSuccess) { ftn_set_error("hipEventElapsedTime: %s", hipGetErrorString(e)); return (int)e; }
+      ms_sum[s] += ms;
+    }
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------- host side
 static int worst_px_per_row(int L, int max_groups) {
   // P_g = L + pad <= 2L - 2; groups have distinct periods
@@ -600,6 +648,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
   const int nblk_mlp = (int)((Nmax + 16 * 2 * 4 - 1) / (16 * 2 * 4));
   const int nblk_ew = 2048;
   int rc;
+  prof_mark(0, st);
   if (pl->mode == 0) {
     const int CA = pl->nbr * pl->MP;
     // A: a = W_in1 x + b
@@ -607,12 +656,14 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = buf0; pa.desc = desc;
     pa.B = B; pa.L = L; pa.C = C; pa.KIN = CP; pa.n_ot = CA / 16; pa.OUTC = CA;
     if ((rc = launch_pw<ACT, true, 0>(pa, xvec, nblk_pw, st))) return rc;
+    prof_mark(1, st);
     // B: m = conv(a)
     ConvArgs ca = {};
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CA; ca.OUTC = CA;
     ca.nbr = pl->nbr; ca.cin = pl->MP; ca.cout = pl->MP; ca.in_stride_br = pl->MP; ca.out_stride_br = pl->MP;
     for (int k = 0; k < pl->nbr; ++k) { ca.W[k] = wb + pl->w_conv1[k]; ca.kh[k] = pl->kh[k]; ca.kw[k] = pl->kw[k]; }
     if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    prof_mark(2, st);
     // C: fused pointwise chain
     MlpArgs ma = {};
     ma.x = x; ma.m = buf1; ma.Wo = wb + pl->w_out1; ma.bo = wb + pl->b_out1;
@@ -622,25 +673,30 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ma.n_oa = CA / 16; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = ma.n_oa + (pl->res2 ? CP / 16 : 0);
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model/mid too large for v1", ma.n_ot); return -1; }
     if ((rc = launch_mlp<ACT>(ma, xvec, nblk_mlp, st))) return rc;
+    prof_mark(3, st);
     // D: m' = conv(a')
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
     if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    prof_mark(4, st);
     // E: delta = act(W_out2 m' + b) + r   (in place over r)
     PwArgs pe = {};
     pe.x = x; pe.in = buf1; pe.W = wb + pl->w_out2; pe.bias = wb + pl->b_out2; pe.R = bufR; pe.desc = desc;
     pe.B = B; pe.L = L; pe.C = C; pe.KIN = CA; pe.n_ot = CP / 16; pe.RC = CP;
     if ((rc = launch_pw<ACT, false, 1>(pe, xvec, nblk_pw, st))) return rc;
+    prof_mark(5, st);
   } else {
     // A: zero-extended copy of x
     hipLaunchKernelGGL(k_embed, dim3(nblk_ew), dim3(256), 0, st, x, buf0, desc, B, L, C, CP);
     FTN_CHECK_LAUNCH();
+    prof_mark(1, st);
     // B: m = conv_merged(x) (+ folded proj bias)
     ConvArgs ca = {};
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CP; ca.OUTC = FP;
     ca.nbr = 1; ca.cin = CP; ca.cout = FP; ca.in_stride_br = 0; ca.out_stride_br = 0;
     ca.W[0] = wb + pl->w_conv1[0]; ca.kh[0] = pl->kh[0]; ca.kw[0] = pl->kw[0];
     if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    prof_mark(2, st);
     // C: g = act(act(m) + res1(x)) -> G ; r = res2(g) - x
     MlpArgs ma = {};
     ma.x = x; ma.m = buf1; ma.Wo = nullptr; ma.bo = nullptr;
@@ -651,17 +707,22 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ma.n_oa = 0; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = pl->res2 ? CP / 16 : 0;
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model too large for v1", ma.n_ot); return -1; }
     if ((rc = launch_mlp<ACT>(ma, xvec, nblk_mlp, st))) return rc;
+    prof_mark(3, st);
     // D: m' = conv_merged'(g)
     ca.in = bufG; ca.out = buf0; ca.bias = wb + pl->b_conv2; ca.INC = FP; ca.OUTC = CP; ca.cin = FP; ca.cout = CP;
     ca.W[0] = wb + pl->w_conv2[0];
     if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    prof_mark(4, st);
     // E: delta = act(m') + r
     hipLaunchKernelGGL(k_final_ident<ACT>, dim3(nblk_ew), dim3(256), 0, st, buf0, bufR, desc, B, CP);
     FTN_CHECK_LAUNCH();
+    prof_mark(5, st);
   }
   // F: y = x + sum_g w delta_g
   hipLaunchKernelGGL(k_combine, dim3(nblk_ew), dim3(256), 0, st, x, y, bufR, wts, desc, B, L, C, CP);
   FTN_CHECK_LAUNCH();
+  prof_mark(6, st);
+  if (g_prof.on && g_prof.calls < FTN_PROF_CALLS) ++g_prof.calls;
   return 0;
 }
 

@@ -125,6 +125,15 @@ int ftn_lrtc_forward(const float* coeff_dev, const float* basis_dev, const float
                      const float* x_dev_or_null, float* out_dev, int B, int L, int N, int R,
                      void* stream);
 
+/* ---- measurement ---------------------------------------------------------------- */
+/* hipEvent brackets around the 6 stages (A pw-in, B conv, C fused pointwise chain,
+ * D conv, E pw-out, F combine) of every following ftn_timesblock_forward call (up to
+ * 512 calls); nothing synchronises until ftn_stage_times is called. */
+int ftn_stage_timing(int enable);
+/* sums, over the calls recorded since ftn_stage_timing(1), of each stage's elapsed
+ * milliseconds; synchronises on the recorded events.  nstage must be 6. */
+int ftn_stage_times(float* ms_sum_host, int nstage, int* ncalls_host);
+
 /* ---- diagnostics --------------------------------------------------------------- */
 /* writes D = A(16x8, a[i][k]=i*8+k+1) * B(8x16, b[k][j]=(k+1)*100+j) via two
  * v_mfma_f32_16x16x4_f32 to out[16][16]: verifies the lane maps the kernels assume */
