@@ -31,19 +31,38 @@ static inline int ftn_pad16(int v) { return (v + 15) & ~15; }
 static inline int ftn_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- conv tiling: one rule shared by the device finalize kernel and the host --
-#define FTN_TILE_PX 256   // max pixels of one conv tile (4 waves x 4 units x 16 px)
-#define FTN_TILE_W 64
-#define FTN_TILE_H 64
+// A conv tile is th x tw grid pixels (<= FTN_TILE_PX: 4 waves x 6 units x 16 px);
+// the kernel stages the tile plus its halo, CLIPPED to the grid, in LDS.  Tiles
+// are as large as possible (a whole 336-pixel grid is one tile) subject to the
+// clipped region (for a 7x7 kernel) staying <= FTN_REGION_PX pixels.
+#define FTN_TILE_PX 384
+#define FTN_REGION_PX 384
+#define FTN_TILE_HALO 3
 
 __host__ __device__ inline void ftn_tile_geometry(int cycles, int period, int* tw, int* th,
                                                   int* ntx, int* nty) {
-  int nx = (period + FTN_TILE_W - 1) / FTN_TILE_W;
-  int w = (period + nx - 1) / nx;
-  int hmax = FTN_TILE_PX / w;
-  if (hmax > FTN_TILE_H) hmax = FTN_TILE_H;
-  if (hmax < 1) hmax = 1;
-  int ny = (cycles + hmax - 1) / hmax;
-  int h = (cycles + ny - 1) / ny;
+  int nx = 1, w = period, h = 1, ny = cycles;
+  for (;; ++nx) {
+    w = (period + nx - 1) / nx;
+    h = FTN_TILE_PX / w;
+    if (h < 1) continue;                       // tile row wider than a tile: split columns further
+    if (h > cycles) h = cycles;
+    ny = (cycles + h - 1) / h;
+    h = (cycles + ny - 1) / ny;
+    // shrink h until the clipped staging region fits
+    for (;;) {
+      int rw = w + 2 * FTN_TILE_HALO; if (rw > period) rw = period;
+      int rh = h + 2 * FTN_TILE_HALO; if (rh > cycles) rh = cycles;
+      if (rw * rh <= FTN_REGION_PX || h == 1) break;
+      --h;
+    }
+    ny = (cycles + h - 1) / h;
+    {
+      int rw = w + 2 * FTN_TILE_HALO; if (rw > period) rw = period;
+      int rh = h + 2 * FTN_TILE_HALO; if (rh > cycles) rh = cycles;
+      if (rw * rh <= FTN_REGION_PX || w <= 8) break;
+    }
+  }
   *tw = w; *th = h; *ntx = nx; *nty = ny;
 }
 

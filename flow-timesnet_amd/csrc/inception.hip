@@ -313,10 +313,19 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
 }
 
 // ---------------------------------------------------------------- stages B / D
+// Grouped k x k convolution as an im2col GEMM.  One workgroup = one conv tile
+// (normally a whole period grid, <= 384 pixels) x one branch x NCO output-channel
+// tiles.  Per 16-input-channel chunk it stages (a) the tile plus halo, clipped to
+// the grid, as [pixel][16 ch] rows of 80 B (16 consecutive pixels hit 16 distinct
+// bank quads on ds_read_b128) and (b) that chunk's weight fragments for every tap,
+// lane-linear (1 KiB per fragment, conflict-free).  A tap outside the grid is conv
+// zero padding: the lane reads a zeroed slot instead (row/column validity bits are
+// precomputed per pixel).  The tap loop is software-pipelined: the next tap's LDS
+// reads are issued before the current tap's MFMAs.
 struct ConvArgs {
   const float* in;       // [N][INC]
   float* out;            // [N][OUTC]
-  const float* W[FTN_MAXBR];   // per branch [taps][ncc][nco][16][16]
+  const float* W[FTN_MAXBR];   // per branch [taps][ncc][nco][lane][4]
   const float* bias;     // [OUTC] (per branch slice at out_off)
   const FtnDesc* desc;
   int B, INC, OUTC;
@@ -326,19 +335,67 @@ struct ConvArgs {
   int in_stride_br;      // channel offset between branches on the input  (cin or 0)
   int out_stride_br;     // channel offset between branches on the output (cout)
   int nchunk;            // output-channel chunks per branch = ceil(cout/16 / NCO)
+  int region_floats;     // LDS floats reserved for the staged region (+ zero slot)
   int kh[FTN_MAXBR], kw[FTN_MAXBR];
+  int order[FTN_MAXBR];  // branches sorted by descending tap count (heavy workgroups first)
 };
 
-#define LDS_PX_STRIDE 20  // 16 channels + 4 pad dwords: ds_read_b128 of 16 pixels hits 16 distinct bank quads
+#define LDS_PX_STRIDE 20  // 16 channels + 4 pad dwords
+#define CONV_NU 6         // 16-pixel units per wave: 4 waves x 6 x 16 = FTN_TILE_PX
+
+template <int NCO, int NU>
+__device__ __forceinline__ void conv_taps(f4 (&acc)[NCO][CONV_NU], const float* __restrict__ tile,
+                                          const float* __restrict__ wl, const int (&lbase)[CONV_NU],
+                                          const unsigned (&rmask)[CONV_NU], const unsigned (&cmask)[CONV_NU],
+                                          int kh, int kw, int RW, int zoff, int lane) {
+  const int hy = kh >> 1, hx = kw >> 1, ntaps = kh * kw;
+  f4 bf[NU], af[NCO];
+  auto loadB = [&](int dy, int dx, f4 (&dst)[NU]) {
+    const int toff = ((dy - hy) * RW + (dx - hx)) * LDS_PX_STRIDE;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const bool v = ((rmask[u] >> dy) & (cmask[u] >> dx) & 1u) != 0u;
+      dst[u] = *(const f4*)(tile + (v ? lbase[u] + toff : zoff));
+    }
+  };
+  auto loadA = [&](int tap, f4 (&dst)[NCO]) {
+#pragma unroll
+    for (int o = 0; o < NCO; ++o) dst[o] = *(const f4*)(wl + (tap * NCO + o) * 256 + lane * 4);
+  };
+  loadB(0, 0, bf);
+  loadA(0, af);
+  int dy = 0, dx = 0;
+  for (int tap = 0; tap < ntaps; ++tap) {
+    int ndx = dx + 1, ndy = dy;
+    if (ndx == kw) { ndx = 0; ++ndy; }
+    const int ntap = tap + 1 < ntaps ? tap + 1 : tap;
+    if (ndy == kh) { ndy = dy; ndx = dx; }
+    f4 bn[NU], an[NCO];
+    loadB(ndy, ndx, bn);
+    loadA(ntap, an);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 0; o < NCO; ++o)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc[o][u] = mfma16(af[o][e], bf[u][e], acc[o][u]);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) bf[u] = bn[u];
+#pragma unroll
+    for (int o = 0; o < NCO; ++o) af[o] = an[o];
+    dy = ndy; dx = ndx;
+  }
+}
 
 template <int NCO>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float tile[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const FtnDesc* __restrict__ d = a.desc;
   const int bx = blockIdx.x;
   if (bx >= d->tiles_per_row) return;   // worst-case grid, data-dependent tile count
   const int b = blockIdx.y;
-  const int br = blockIdx.z / a.nchunk, chunk = blockIdx.z - br * a.nchunk;
+  const int zb = blockIdx.z / a.nchunk, chunk = blockIdx.z - zb * a.nchunk;
+  const int br = a.order[zb];
   const int G = d->n_groups;
   int g = 0;
   for (int gg = 1; gg < G; ++gg)
@@ -351,71 +408,76 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   const int r0 = ty * d->g_th[g], c0 = tx * d->g_tw[g];
   const int th = min(d->g_th[g], cycles - r0), tw = min(d->g_tw[g], p - c0);
   const int kh = a.kh[br], kw = a.kw[br], hy = kh >> 1, hx = kw >> 1;
-  const int SW = tw + 2 * hx, SH = th + 2 * hy;
+  // staged region = tile + halo, clipped to the grid
+  const int R0 = max(0, r0 - hy), R1 = min(cycles, r0 + th + hy);
+  const int C0 = max(0, c0 - hx), C1 = min(p, c0 + tw + hx);
+  const int RW = C1 - C0, RH = R1 - R0;
+  float* __restrict__ tile = lds;
+  float* __restrict__ wl = lds + a.region_floats;
+  const int zoff = a.region_floats - 16;                 // 16 zero floats at the end of the region area
   const size_t nimg = (size_t)a.B * d->g_px_off[g] + (size_t)b * P;
   const float* __restrict__ in = a.in + nimg * a.INC + br * a.in_stride_br;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int npx = th * tw, nunits = (npx + 15) >> 4;
+  const int nu = nunits > wave ? (nunits - wave + 3) >> 2 : 0;   // units of this wave: wave, wave+4, ...
   const int nco_tot = a.cout >> 4, co0 = chunk * NCO;
-  const int ncc = a.cin >> 4;
+  const int ncc = a.cin >> 4, ntaps = kh * kw;
 
-  // this lane's pixels: unit u of this wave is tile pixels 16*(wave + 4u) + j
-  int lbase[NPXU], oidx[NPXU];
-  bool uok[NPXU], pok[NPXU];
+  int lbase[CONV_NU], oidx[CONV_NU];
+  unsigned rmask[CONV_NU], cmask[CONV_NU];
+  bool pok[CONV_NU];
 #pragma unroll
-  for (int u = 0; u < NPXU; ++u) {
-    const int unit = wave + 4 * u;
-    uok[u] = unit < nunits;
-    int idx = unit * 16 + j;
+  for (int u = 0; u < CONV_NU; ++u) {
+    int idx = (wave + 4 * u) * 16 + j;
     pok[u] = idx < npx;
     if (!pok[u]) idx = 0;
     const int r = idx / tw, c = idx - r * tw;
-    lbase[u] = (r * SW + c) * LDS_PX_STRIDE + 4 * q;     // top-left tap of this pixel
-    oidx[u] = (r0 + r) * p + c0 + c;
+    const int ri = r0 + r, ci = c0 + c;
+    lbase[u] = ((ri - R0) * RW + (ci - C0)) * LDS_PX_STRIDE + 4 * q;
+    oidx[u] = ri * p + ci;
+    unsigned rm = 0, cm = 0;
+    for (int dy = 0; dy < kh; ++dy) { const int rr = ri + dy - hy; rm |= (rr >= 0 && rr < cycles) ? (1u << dy) : 0u; }
+    for (int dx = 0; dx < kw; ++dx) { const int cx = ci + dx - hx; cm |= (cx >= 0 && cx < p) ? (1u << dx) : 0u; }
+    rmask[u] = pok[u] ? rm : 0u;
+    cmask[u] = pok[u] ? cm : 0u;
   }
-  f4 acc[NCO][NPXU];
+  f4 acc[NCO][CONV_NU];
 #pragma unroll
   for (int o = 0; o < NCO; ++o) {
     f4 bv = {0.f, 0.f, 0.f, 0.f};
     if (co0 + o < nco_tot) bv = *(const f4*)(a.bias + br * a.out_stride_br + 16 * (co0 + o) + 4 * q);
 #pragma unroll
-    for (int u = 0; u < NPXU; ++u) acc[o][u] = bv;
+    for (int u = 0; u < CONV_NU; ++u) acc[o][u] = bv;
   }
+  if (threadIdx.x < 4) *(f4*)(tile + zoff + 4 * threadIdx.x) = f4{0.f, 0.f, 0.f, 0.f};
   const float* __restrict__ Wb = a.W[br];
-  const int nstage = SH * SW * 4;
+  const int nstage = RH * RW * 4;
+  const int nwst = ntaps * NCO * 64;
   for (int cc = 0; cc < ncc; ++cc) {
     if (cc > 0) __syncthreads();
-    // stage 16 input channels of the tile + halo; outside the grid = conv zero padding
     for (int s = threadIdx.x; s < nstage; s += 256) {
       const int sp = s >> 2, qq = s & 3;
-      const int rr = sp / SW, cx = sp - rr * SW;
-      const int row = r0 - hy + rr, col = c0 - hx + cx;
+      const int rr = sp / RW, cx = sp - rr * RW;
+      *(f4*)(tile + sp * LDS_PX_STRIDE + 4 * qq) =
+          *(const f4*)(in + (size_t)((R0 + rr) * p + C0 + cx) * a.INC + 16 * cc + 4 * qq);
+    }
+    for (int s = threadIdx.x; s < nwst; s += 256) {
+      const int tap = s / (NCO * 64), rem = s - tap * (NCO * 64);
+      const int o = rem >> 6;
       f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (row >= 0 && row < cycles && col >= 0 && col < p)
-        v = *(const f4*)(in + (size_t)(row * p + col) * a.INC + 16 * cc + 4 * qq);
-      *(f4*)(tile + sp * LDS_PX_STRIDE + 4 * qq) = v;
+      if (co0 + o < nco_tot)
+        v = *(const f4*)(Wb + ((size_t)(tap * ncc + cc) * nco_tot + co0 + o) * 256 + (rem & 63) * 4);
+      *(f4*)(wl + (size_t)s * 4) = v;
     }
     __syncthreads();
-    for (int dy = 0; dy < kh; ++dy) {
-      for (int dx = 0; dx < kw; ++dx) {
-        const int tapoff = (dy * SW + dx) * LDS_PX_STRIDE;
-        f4 bf[NPXU];
-#pragma unroll
-        for (int u = 0; u < NPXU; ++u)
-          if (uok[u]) bf[u] = *(const f4*)(tile + lbase[u] + tapoff);
-        const float* __restrict__ wt = Wb + ((size_t)((dy * kw + dx) * ncc + cc) * nco_tot + co0) * 256 + lane * 4;
-#pragma unroll
-        for (int o = 0; o < NCO; ++o) {
-          if (co0 + o < nco_tot) {
-            const f4 af = *(const f4*)(wt + o * 256);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-              for (int u = 0; u < NPXU; ++u)
-                if (uok[u]) acc[o][u] = mfma16(af[e], bf[u][e], acc[o][u]);
-          }
-        }
-      }
+    switch (nu) {
+      case 6: conv_taps<NCO, 6>(acc, tile, wl, lbase, rmask, cmask, kh, kw, RW, zoff, lane); break;
+      case 5: conv_taps<NCO, 5>(acc, tile, wl, lbase, rmask, cmask, kh, kw, RW, zoff, lane); break;
+      case 4: conv_taps<NCO, 4>(acc, tile, wl, lbase, rmask, cmask, kh, kw, RW, zoff, lane); break;
+      case 3: conv_taps<NCO, 3>(acc, tile, wl, lbase, rmask, cmask, kh, kw, RW, zoff, lane); break;
+      case 2: conv_taps<NCO, 2>(acc, tile, wl, lbase, rmask, cmask, kh, kw, RW, zoff, lane); break;
+      case 1: conv_taps<NCO, 1>(acc, tile, wl, lbase, rmask, cmask, kh, kw, RW, zoff, lane); break;
+      default: break;
     }
   }
   float* __restrict__ out = a.out + nimg * a.OUTC + br * a.out_stride_br;
@@ -423,8 +485,8 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   for (int o = 0; o < NCO; ++o) {
     if (co0 + o < nco_tot) {
 #pragma unroll
-      for (int u = 0; u < NPXU; ++u)
-        if (uok[u] && pok[u]) *(f4*)(out + (size_t)oidx[u] * a.OUTC + 16 * (co0 + o) + 4 * q) = acc[o][u];
+      for (int u = 0; u < CONV_NU; ++u)
+        if (u < nu && pok[u]) *(f4*)(out + (size_t)oidx[u] * a.OUTC + 16 * (co0 + o) + 4 * q) = acc[o][u];
     }
   }
 }
@@ -546,16 +608,21 @@ static void worst_tiles(int L, int max_groups, int* tiles_per_row) {
   *tiles_per_row = sum > 0 ? sum : 1;
 }
 
-static size_t conv_lds_bytes(int kh, int kw) {
-  // worst staged tile: (th+2hy)*(tw+2hx) with th*tw <= FTN_TILE_PX, th,tw <= 64
-  size_t worst = 0;
-  for (int tw = 1; tw <= FTN_TILE_W; ++tw) {
-    int th = FTN_TILE_PX / tw;
-    if (th > FTN_TILE_H) th = FTN_TILE_H;
-    size_t px = (size_t)(th + 2 * (kh / 2)) * (tw + 2 * (kw / 2));
-    if (px > worst) worst = px;
+// Worst staged region (pixels) of a kh x kw conv over every valid period of a
+// window of length L, with the tile geometry of ftn_tile_geometry.
+static int conv_region_px(int L, int kh, int kw) {
+  int worst = 1;
+  const int hy = kh / 2, hx = kw / 2;
+  for (int p = 1; p < L; ++p) {
+    int pad = (p - (L % p)) % p, cyc = (L + pad) / p;
+    if (cyc < 2) continue;
+    int tw, th, ntx, nty;
+    ftn_tile_geometry(cyc, p, &tw, &th, &ntx, &nty);
+    int rw = tw + 2 * hx; if (rw > p) rw = p;
+    int rh = th + 2 * hy; if (rh > cyc) rh = cyc;
+    if (rw * rh > worst) worst = rw * rh;
   }
-  return worst * LDS_PX_STRIDE * sizeof(float);
+  return worst;
 }
 
 struct WsLayout {
@@ -594,16 +661,30 @@ static int launch_conv_t(const ConvArgs& ca, dim3 grid, size_t lds, hipStream_t 
   return 0;
 }
 
-static int launch_conv(ConvArgs& ca, int B, int tiles_per_row, hipStream_t st) {
+static int launch_conv(ConvArgs& ca, int B, int L, int tiles_per_row, hipStream_t st) {
   const int nco_tot = ca.cout / 16;
-  const int NCO = nco_tot >= 4 ? 4 : (nco_tot >= 2 ? 2 : 1);
-  ca.nchunk = ftn_cdiv(nco_tot, NCO);
-  size_t lds = 0;
+  int region_px = 1, max_taps = 1;
   for (int k = 0; k < ca.nbr; ++k) {
-    size_t v = conv_lds_bytes(ca.kh[k], ca.kw[k]);
-    if (v > lds) lds = v;
+    int v = conv_region_px(L, ca.kh[k], ca.kw[k]);
+    if (v > region_px) region_px = v;
+    if (ca.kh[k] * ca.kw[k] > max_taps) max_taps = ca.kh[k] * ca.kw[k];
+    if (ca.kh[k] > 31 || ca.kw[k] > 31) { ftn_set_error("conv kernel %dx%d too large", ca.kh[k], ca.kw[k]); return -1; }
   }
-  if (lds > 160 * 1024) { ftn_set_error("conv kernel %dx%d needs %zu B of LDS", ca.kh[0], ca.kw[0], lds); return -1; }
+  ca.region_floats = ((region_px * LDS_PX_STRIDE + 16) + 63) & ~63;
+  // output-channel tiles per workgroup: as many as keep the weight fragments (taps*NCO KiB) + region in LDS
+  int NCO = nco_tot >= 4 ? 4 : (nco_tot >= 2 ? 2 : 1);
+  const size_t budget = 96 * 1024;
+  while (NCO > 1 && (size_t)ca.region_floats * 4 + (size_t)max_taps * NCO * 1024 > budget) NCO >>= 1;
+  const size_t lds = (size_t)ca.region_floats * 4 + (size_t)max_taps * NCO * 1024;
+  if (lds > 160 * 1024) { ftn_set_error("conv kernel needs %zu B of LDS (kernel too large)", lds); return -1; }
+  ca.nchunk = ftn_cdiv(nco_tot, NCO);
+  // heavy branches first
+  for (int k = 0; k < ca.nbr; ++k) ca.order[k] = k;
+  for (int i = 1; i < ca.nbr; ++i) {
+    int v = ca.order[i], jj = i - 1;
+    while (jj >= 0 && ca.kh[ca.order[jj]] * ca.kw[ca.order[jj]] < ca.kh[v] * ca.kw[v]) { ca.order[jj + 1] = ca.order[jj]; --jj; }
+    ca.order[jj + 1] = v;
+  }
   dim3 grid(tiles_per_row, B, ca.nbr * ca.nchunk);
   if (NCO == 4) return launch_conv_t<4>(ca, grid, lds, st);
   if (NCO == 2) return launch_conv_t<2>(ca, grid, lds, st);
@@ -662,7 +743,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CA; ca.OUTC = CA;
     ca.nbr = pl->nbr; ca.cin = pl->MP; ca.cout = pl->MP; ca.in_stride_br = pl->MP; ca.out_stride_br = pl->MP;
     for (int k = 0; k < pl->nbr; ++k) { ca.W[k] = wb + pl->w_conv1[k]; ca.kh[k] = pl->kh[k]; ca.kw[k] = pl->kw[k]; }
-    if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
     prof_mark(2, st);
     // C: fused pointwise chain
     MlpArgs ma = {};
@@ -677,7 +758,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // D: m' = conv(a')
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
-    if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
     prof_mark(4, st);
     // E: delta = act(W_out2 m' + b) + r   (in place over r)
     PwArgs pe = {};
@@ -695,7 +776,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CP; ca.OUTC = FP;
     ca.nbr = 1; ca.cin = CP; ca.cout = FP; ca.in_stride_br = 0; ca.out_stride_br = 0;
     ca.W[0] = wb + pl->w_conv1[0]; ca.kh[0] = pl->kh[0]; ca.kw[0] = pl->kw[0];
-    if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
     prof_mark(2, st);
     // C: g = act(act(m) + res1(x)) -> G ; r = res2(g) - x
     MlpArgs ma = {};
@@ -711,7 +792,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // D: m' = conv_merged'(g)
     ca.in = bufG; ca.out = buf0; ca.bias = wb + pl->b_conv2; ca.INC = FP; ca.OUTC = CP; ca.cin = FP; ca.cout = CP;
     ca.W[0] = wb + pl->w_conv2[0];
-    if ((rc = launch_conv(ca, B, tiles_row, st))) return rc;
+    if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
     prof_mark(4, st);
     // E: delta = act(m') + r
     hipLaunchKernelGGL(k_final_ident<ACT>, dim3(nblk_ew), dim3(256), 0, st, buf0, bufR, desc, B, CP);

@@ -105,12 +105,24 @@ __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, i
   }
 }
 
-__global__ void k_colsum(const float* __restrict__ med, int B, int F, double* __restrict__ psum) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
+// psum[f] = sum_b med[b][f] in fp64, fixed order: 8 row-strided partial sums per
+// column, combined in index order (bitwise reproducible; no atomics).
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ med, int B, int F,
+                                                double* __restrict__ psum) {
+  __shared__ double part[8][32];
+  const int fl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  const int f = blockIdx.x * 32 + fl;
   double s = 0.0;
-  for (int b = 0; b < B; ++b) s += (double)med[(size_t)b * F + f];
-  psum[f] = s;
+  if (f < F)
+    for (int b = bl; b < B; b += 8) s += (double)med[(size_t)b * F + f];
+  part[bl][fl] = s;
+  __syncthreads();
+  if (bl == 0 && f < F) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][fl];
+    psum[f] = t;
+  }
 }
 
 extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* table_dev,
@@ -130,7 +142,7 @@ extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, cons
   hipLaunchKernelGGL(k_spectrum, dim3(FPAD / 32, B), dim3(64 * nw), lds, (hipStream_t)stream, x_dev, L, C,
                      (const float*)table_dev, F, FPAD, med_dev);
   FTN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_colsum, dim3(ftn_cdiv(F, 64)), dim3(64), 0, (hipStream_t)stream, med_dev, B, F, psum_dev);
+  hipLaunchKernelGGL(k_colsum, dim3(ftn_cdiv(F, 32)), dim3(256), 0, (hipStream_t)stream, med_dev, B, F, psum_dev);
   FTN_CHECK_LAUNCH();
   return 0;
 }

@@ -53,7 +53,7 @@ def test_descriptor_matches_oracle_grouping(ftn, periods, L):
     assert d.total_px == sum(L + p for p in g.pad)
     for i in range(G):  # tiles cover the grid, respect the size limits
         assert d.g_tw[i] * d.g_ntx[i] >= g.periods[i] and d.g_th[i] * d.g_nty[i] >= g.cycles[i]
-        assert d.g_tw[i] * d.g_th[i] <= 256 and d.g_tw[i] <= 64 and d.g_th[i] <= 64
+        assert d.g_tw[i] * d.g_th[i] <= 384
         assert d.g_tw[i] * (d.g_ntx[i] - 1) < g.periods[i] and d.g_th[i] * (d.g_nty[i] - 1) < g.cycles[i]
 
 
