@@ -141,73 +141,100 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
 }
 
 // ---------------------------------------------------------------- stage C
+// g  = act(act(W_out1 m + b) + W_res1 x + b)       hidden, d_ff channels
+// a' = W_in2 g + b ;  r = W_res2 g + b - x         the stacked output projection W_c
+// One wave owns NPX 16-pixel units; the hidden dimension is walked in chunks of
+// 64 channels (4 MFMA row tiles).  Per chunk the workgroup stages that chunk's
+// weight fragments (lane-linear, pre-packed on the host: FtnPlan.w_cfrag) in LDS
+// once for its 4 waves; layer 1 and the residual read their B fragments (m, x
+// rows) straight from global/L2 with a one-step-ahead prefetch; the hidden
+// accumulators then ARE the B fragments of the output projection, which
+// accumulates across chunks in registers.  Nothing hidden-sized touches memory.
 struct MlpArgs {
   const float* x;
   const float* m;        // [N][KM] conv output of block 1
-  const float* Wo;       // w_out1 [FP][KM]   (null: z = m, KM == FP)
-  const float* bo;
-  const float* Wr;       // w_res1 [FP][CP]   (null: res = x, FP == CP)
-  const float* br;
-  const float* Wc;       // stage-C output projection [16*n_ot][FP]
-  const float* bc;
+  const float* cfrag;    // [n_hchunks][cfrag_per_chunk][256]
+  const float* bo;       // [FP] bias of W_out1 (null when z = m)
+  const float* br;       // [FP] bias of W_res1 (null when res = x)
+  const float* bc;       // [16*n_ot]
   float* outA;           // [N][AC]: first n_oa output tiles (a'), may be null
   float* outG;           // [N][FP]: hidden store (single-conv mode), may be null
   float* outR;           // [N][CP]: r = res2(g) - x
   const FtnDesc* desc;
   int B, L, C, CP, FP, KM, AC;
+  int nKM;               // K chunks of layer 1 (KM/16), 0: z = m (KM == FP)
+  int nCP;               // K chunks of the residual (CP/16), 0: res = x (FP == CP)
   int n_oa;              // output tiles that go to outA
   int n_ot;              // total output tiles (n_oa + CP/16 when res2 is a conv)
   int res2_ident;        // 1: r = g - x  (FP == CP), taken from the hidden tiles
+  int n_hchunks, cfrag_per_chunk;
 };
 
-template <int ACT, bool XVEC, int OTM>
-__global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
-  constexpr int NPX = 2, HT = 4;
+template <int ACT, bool XVEC, int NPX, int OTM, bool EXACT>
+__global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
+  constexpr int HT = 4;
+  extern __shared__ __attribute__((aligned(16))) float wl[];
   const FtnDesc* __restrict__ d = a.desc;
   const int N = a.B * d->total_px;
+  if ((int)(blockIdx.x * 4 * 16 * NPX) >= N) return;            // whole workgroup beyond the live pixels
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int n0 = (blockIdx.x * 4 + wave) * (16 * NPX);
-  if (n0 >= N) return;
+  const bool active = n0 < N;                                    // wave-uniform; idle waves still stage + sync
   Px px[NPX];
 #pragma unroll
   for (int u = 0; u < NPX; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
   const int FP = a.FP, KM = a.KM, CP = a.CP;
   const int nht = FP >> 4;
+  const int nKM = a.nKM, nCP = a.nCP, n_ot = EXACT ? OTM : a.n_ot;
+  const int offWr = HT * nKM, offWc = offWr + HT * nCP;
+  const float* __restrict__ wlane = wl + lane * 4;
 
   f4 oacc[OTM][NPX];
 #pragma unroll
   for (int o = 0; o < OTM; ++o) {
     f4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (o < a.n_ot) bv = *(const f4*)(a.bc + 16 * o + 4 * q);
+    if (o < n_ot) bv = *(const f4*)(a.bc + 16 * o + 4 * q);
 #pragma unroll
     for (int u = 0; u < NPX; ++u) oacc[o][u] = bv;
   }
 
-  for (int hc = 0; hc < nht; hc += HT) {
+  const int nstage = a.cfrag_per_chunk * 64;
+  for (int hc = 0; hc < a.n_hchunks; ++hc) {
+    __syncthreads();
+    {
+      const float* __restrict__ src = a.cfrag + (size_t)hc * a.cfrag_per_chunk * 256;
+      for (int i = threadIdx.x; i < nstage; i += 256) *(f4*)(wl + (size_t)i * 4) = *(const f4*)(src + (size_t)i * 4);
+    }
+    __syncthreads();
+    if (!active) continue;
     f4 h[HT][NPX];
     // ---- z = W_out1 m + b   (or z = m)
-    if (a.Wo != nullptr) {
+    if (nKM > 0) {
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
         f4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (hc + t < nht) bv = *(const f4*)(a.bo + 16 * (hc + t) + 4 * q);
+        if (hc * HT + t < nht) bv = *(const f4*)(a.bo + 16 * (hc * HT + t) + 4 * q);
 #pragma unroll
         for (int u = 0; u < NPX; ++u) h[t][u] = bv;
       }
-      for (int s = 0; s < KM; s += 16) {
-        f4 bf[NPX];
+      f4 bcur[NPX];
 #pragma unroll
-        for (int u = 0; u < NPX; ++u) bf[u] = *(const f4*)(a.m + (size_t)px[u].n * KM + s + 4 * q);
+      for (int u = 0; u < NPX; ++u) bcur[u] = *(const f4*)(a.m + (size_t)px[u].n * KM + 4 * q);
+      for (int s = 0; s < nKM; ++s) {
+        const int sn = s + 1 < nKM ? s + 1 : s;
+        f4 bnxt[NPX];
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) bnxt[u] = *(const f4*)(a.m + (size_t)px[u].n * KM + 16 * sn + 4 * q);
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
-          if (hc + t < nht) {
-            const f4 af = *(const f4*)(a.Wo + (size_t)(16 * (hc + t) + j) * KM + s + 4 * q);
+          const f4 af = *(const f4*)(wlane + (t * nKM + s) * 256);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bf[u][e], h[t][u]);
-          }
+            for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bcur[u][e], h[t][u]);
         }
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) bcur[u] = bnxt[u];
       }
     } else {
 #pragma unroll
@@ -215,7 +242,7 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
 #pragma unroll
         for (int u = 0; u < NPX; ++u) {
           f4 v = {0.f, 0.f, 0.f, 0.f};
-          if (hc + t < nht) v = *(const f4*)(a.m + (size_t)px[u].n * KM + 16 * (hc + t) + 4 * q);
+          if (hc * HT + t < nht) v = *(const f4*)(a.m + (size_t)px[u].n * KM + 16 * (hc * HT + t) + 4 * q);
           h[t][u] = v;
         }
     }
@@ -224,36 +251,40 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
     for (int t = 0; t < HT; ++t)
 #pragma unroll
       for (int u = 0; u < NPX; ++u) h[t][u] = act4<ACT>(h[t][u]);
-    if (a.Wr != nullptr) {
+    if (nCP > 0) {
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        if (hc + t < nht) {
-          const f4 bv = *(const f4*)(a.br + 16 * (hc + t) + 4 * q);
+        if (hc * HT + t < nht) {
+          const f4 bv = *(const f4*)(a.br + 16 * (hc * HT + t) + 4 * q);
 #pragma unroll
           for (int u = 0; u < NPX; ++u) h[t][u] += bv;
         }
       }
-      for (int s = 0; s < CP; s += 16) {
-        f4 bf[NPX];
+      f4 bcur[NPX];
 #pragma unroll
-        for (int u = 0; u < NPX; ++u) bf[u] = load_x4<XVEC>(px[u].xrow, s + 4 * q, a.C);
+      for (int u = 0; u < NPX; ++u) bcur[u] = load_x4<XVEC>(px[u].xrow, 4 * q, a.C);
+      for (int s = 0; s < nCP; ++s) {
+        const int sn = s + 1 < nCP ? s + 1 : s;
+        f4 bnxt[NPX];
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) bnxt[u] = load_x4<XVEC>(px[u].xrow, 16 * sn + 4 * q, a.C);
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
-          if (hc + t < nht) {
-            const f4 af = *(const f4*)(a.Wr + (size_t)(16 * (hc + t) + j) * CP + s + 4 * q);
+          const f4 af = *(const f4*)(wlane + (offWr + t * nCP + s) * 256);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bf[u][e], h[t][u]);
-          }
+            for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bcur[u][e], h[t][u]);
         }
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) bcur[u] = bnxt[u];
       }
     } else {
 #pragma unroll
       for (int t = 0; t < HT; ++t)
 #pragma unroll
         for (int u = 0; u < NPX; ++u)
-          if (hc + t < nht) h[t][u] += load_x4<XVEC>(px[u].xrow, 16 * (hc + t) + 4 * q, a.C);
+          if (hc * HT + t < nht) h[t][u] += load_x4<XVEC>(px[u].xrow, 16 * (hc * HT + t) + 4 * q, a.C);
     }
     // ---- mid activation                           (:753)
 #pragma unroll
@@ -264,11 +295,11 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
     if (a.outG != nullptr || a.res2_ident) {
 #pragma unroll
       for (int t = 0; t < HT; ++t) {
-        if (hc + t < nht) {
+        if (hc * HT + t < nht) {
 #pragma unroll
           for (int u = 0; u < NPX; ++u) {
             if (!px[u].ok) continue;
-            const int ch = 16 * (hc + t) + 4 * q;
+            const int ch = 16 * (hc * HT + t) + 4 * q;
             if (a.outG != nullptr) *(f4*)(a.outG + (size_t)px[u].n * FP + ch) = h[t][u];
             if (a.res2_ident)
               *(f4*)(a.outR + (size_t)px[u].n * CP + ch) = h[t][u] - load_x4<XVEC>(px[u].xrow, ch, a.C);
@@ -276,28 +307,26 @@ __global__ __launch_bounds__(256) void k_mlp(MlpArgs a) {
         }
       }
     }
-    // ---- output projection accumulates over hidden chunks: the hidden
-    //      accumulator registers ARE the B fragments (k = 16(hc+t)+4q+r)
+    // ---- output projection: the hidden accumulators ARE the B fragments
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
-      if (hc + t < nht) {
 #pragma unroll
-        for (int o = 0; o < OTM; ++o) {
-          if (o < a.n_ot) {
-            const f4 af = *(const f4*)(a.Wc + (size_t)(16 * o + j) * FP + 16 * (hc + t) + 4 * q);
+      for (int o = 0; o < OTM; ++o) {
+        if (EXACT || o < n_ot) {
+          const f4 af = *(const f4*)(wlane + (offWc + t * n_ot + o) * 256);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int u = 0; u < NPX; ++u) oacc[o][u] = mfma16(af[e], h[t][u][e], oacc[o][u]);
-          }
+            for (int u = 0; u < NPX; ++u) oacc[o][u] = mfma16(af[e], h[t][u][e], oacc[o][u]);
         }
       }
     }
   }
+  if (!active) return;
   // ---- epilogue: a' tiles, then r = res2(g) - x tiles
 #pragma unroll
   for (int o = 0; o < OTM; ++o) {
-    if (o < a.n_ot) {
+    if (EXACT || o < n_ot) {
 #pragma unroll
       for (int u = 0; u < NPX; ++u) {
         if (!px[u].ok) continue;
@@ -699,17 +728,33 @@ static int launch_pw(const PwArgs& pa, bool xvec, int nblk, hipStream_t st) {
   return 0;
 }
 
-template <int ACT>
-static int launch_mlp(const MlpArgs& ma, bool xvec, int nblk, hipStream_t st) {
-  if (ma.n_ot <= 8) {
-    if (xvec) hipLaunchKernelGGL((k_mlp<ACT, true, 8>), dim3(nblk), dim3(256), 0, st, ma);
-    else hipLaunchKernelGGL((k_mlp<ACT, false, 8>), dim3(nblk), dim3(256), 0, st, ma);
-  } else {
-    if (xvec) hipLaunchKernelGGL((k_mlp<ACT, true, 16>), dim3(nblk), dim3(256), 0, st, ma);
-    else hipLaunchKernelGGL((k_mlp<ACT, false, 16>), dim3(nblk), dim3(256), 0, st, ma);
+template <int ACT, bool XVEC, int NPX, int OTM, bool EXACT>
+static int launch_mlp_t(const MlpArgs& ma, long long Nmax, hipStream_t st) {
+  const size_t lds = (size_t)ma.cfrag_per_chunk * 1024;
+  if (lds > 160 * 1024) { ftn_set_error("stage C needs %zu B of LDS per hidden chunk", lds); return -1; }
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<ACT, XVEC, NPX, OTM, EXACT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp): %s", hipGetErrorString(e)); return (int)e; }
   }
+  const int per = 16 * NPX * 4;
+  const int nblk = (int)((Nmax + per - 1) / per);
+  hipLaunchKernelGGL((k_mlp<ACT, XVEC, NPX, OTM, EXACT>), dim3(nblk), dim3(256), lds, st, ma);
   FTN_CHECK_LAUNCH();
   return 0;
+}
+
+template <int ACT, bool XVEC>
+static int launch_mlp_x(const MlpArgs& ma, long long Nmax, hipStream_t st) {
+  if (ma.n_ot == 7) return launch_mlp_t<ACT, XVEC, 3, 7, true>(ma, Nmax, st);     // d_model 64, mid 16, 3 kernels
+  if (ma.n_ot <= 8) return launch_mlp_t<ACT, XVEC, 3, 8, false>(ma, Nmax, st);
+  if (ma.n_ot == 14) return launch_mlp_t<ACT, XVEC, 2, 14, true>(ma, Nmax, st);   // d_model 128, mid 32, 3 kernels
+  return launch_mlp_t<ACT, XVEC, 2, 16, false>(ma, Nmax, st);
+}
+
+template <int ACT>
+static int launch_mlp(const MlpArgs& ma, bool xvec, long long Nmax, hipStream_t st) {
+  return xvec ? launch_mlp_x<ACT, true>(ma, Nmax, st) : launch_mlp_x<ACT, false>(ma, Nmax, st);
 }
 
 template <int ACT>
@@ -726,7 +771,6 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
   int tiles_row;
   worst_tiles(L, max_groups, &tiles_row);
   const int nblk_pw = (int)((Nmax + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));
-  const int nblk_mlp = (int)((Nmax + 16 * 2 * 4 - 1) / (16 * 2 * 4));
   const int nblk_ew = 2048;
   int rc;
   prof_mark(0, st);
@@ -747,13 +791,16 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     prof_mark(2, st);
     // C: fused pointwise chain
     MlpArgs ma = {};
-    ma.x = x; ma.m = buf1; ma.Wo = wb + pl->w_out1; ma.bo = wb + pl->b_out1;
-    ma.Wr = pl->res1 ? wb + pl->w_res1 : nullptr; ma.br = pl->res1 ? wb + pl->b_res1 : nullptr;
-    ma.Wc = wb + pl->w_c2; ma.bc = wb + pl->b_c2; ma.outA = buf0; ma.outG = nullptr; ma.outR = bufR; ma.desc = desc;
+    ma.x = x; ma.m = buf1; ma.cfrag = wb + pl->w_cfrag; ma.bo = wb + pl->b_out1;
+    ma.br = pl->res1 ? wb + pl->b_res1 : nullptr;
+    ma.bc = wb + pl->b_c2; ma.outA = buf0; ma.outG = nullptr; ma.outR = bufR; ma.desc = desc;
     ma.B = B; ma.L = L; ma.C = C; ma.CP = CP; ma.FP = FP; ma.KM = CA; ma.AC = CA;
+    ma.nKM = CA / 16; ma.nCP = pl->res1 ? CP / 16 : 0;
+    ma.n_hchunks = pl->n_hchunks; ma.cfrag_per_chunk = pl->cfrag_per_chunk;
     ma.n_oa = CA / 16; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = ma.n_oa + (pl->res2 ? CP / 16 : 0);
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model/mid too large for v1", ma.n_ot); return -1; }
-    if ((rc = launch_mlp<ACT>(ma, xvec, nblk_mlp, st))) return rc;
+    if (ma.cfrag_per_chunk != 4 * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
+    if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
     prof_mark(3, st);
     // D: m' = conv(a')
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
@@ -780,14 +827,17 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     prof_mark(2, st);
     // C: g = act(act(m) + res1(x)) -> G ; r = res2(g) - x
     MlpArgs ma = {};
-    ma.x = x; ma.m = buf1; ma.Wo = nullptr; ma.bo = nullptr;
-    ma.Wr = pl->res1 ? wb + pl->w_res1 : nullptr; ma.br = pl->res1 ? wb + pl->b_res1 : nullptr;
-    ma.Wc = pl->res2 ? wb + pl->w_res2 : nullptr; ma.bc = pl->res2 ? wb + pl->b_res2 : nullptr;
+    ma.x = x; ma.m = buf1; ma.cfrag = wb + pl->w_cfrag; ma.bo = nullptr;
+    ma.br = pl->res1 ? wb + pl->b_res1 : nullptr;
+    ma.bc = pl->res2 ? wb + pl->b_res2 : nullptr;
     ma.outA = nullptr; ma.outG = bufG; ma.outR = bufR; ma.desc = desc;
     ma.B = B; ma.L = L; ma.C = C; ma.CP = CP; ma.FP = FP; ma.KM = FP; ma.AC = 0;
+    ma.nKM = 0; ma.nCP = pl->res1 ? CP / 16 : 0;
+    ma.n_hchunks = pl->n_hchunks; ma.cfrag_per_chunk = pl->cfrag_per_chunk;
     ma.n_oa = 0; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = pl->res2 ? CP / 16 : 0;
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model too large for v1", ma.n_ot); return -1; }
-    if ((rc = launch_mlp<ACT>(ma, xvec, nblk_mlp, st))) return rc;
+    if (ma.cfrag_per_chunk != 4 * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
+    if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
     prof_mark(3, st);
     // D: m' = conv_merged'(g)
     ca.in = bufG; ca.out = buf0; ca.bias = wb + pl->b_conv2; ca.INC = FP; ca.OUTC = CP; ca.cin = FP; ca.cout = CP;

@@ -13,7 +13,7 @@ from typing import Optional
 
 FTN_KMAX = 16
 FTN_MAXBR = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libflowtimes_hip.so"
@@ -57,6 +57,7 @@ class FtnPlan(C.Structure):
         ("w_out2", C.c_int64), ("b_out2", C.c_int64),
         ("w_res2", C.c_int64), ("b_res2", C.c_int64),
         ("w_c2", C.c_int64), ("b_c2", C.c_int64),
+        ("w_cfrag", C.c_int64), ("cfrag_per_chunk", C.c_int32), ("n_hchunks", C.c_int32),
         ("total_floats", C.c_int64),
     ]
 

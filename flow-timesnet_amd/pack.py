@@ -65,6 +65,36 @@ def _pack_conv(w: np.ndarray, cinP: int, coutP: int) -> np.ndarray:
     return np.ascontiguousarray(v).astype(np.float32)
 
 
+def _frag(W: np.ndarray, R: int, S: int) -> np.ndarray:
+    """16x16 block (rows 16R.., cols 16S..) of W as a lane-linear MFMA A fragment:
+    [lane = 16*q + j][e] = W[16R + j][16S + 4q + e]; zero outside W."""
+    blk = np.zeros((16, 16))
+    r0, c0 = 16 * R, 16 * S
+    if r0 < W.shape[0] and c0 < W.shape[1]:
+        sub = W[r0:r0 + 16, c0:c0 + 16]
+        blk[:sub.shape[0], :sub.shape[1]] = sub
+    return blk.reshape(16, 4, 4).transpose(1, 0, 2).reshape(-1)
+
+
+def _pack_cfrag(W_out, W_res, W_c, FP: int, nKM: int, nCP: int, n_ot: int) -> np.ndarray:
+    """Stage-C fragments grouped per 64-channel hidden chunk (see FtnPlan.w_cfrag)."""
+    nch = (FP + 63) // 64
+    per = 4 * (nKM + nCP + n_ot)
+    out = np.zeros((nch, max(per, 1), 256))
+    for hc in range(nch):
+        k = 0
+        for t in range(4):
+            for s_ in range(nKM):
+                out[hc, k] = _frag(W_out, hc * 4 + t, s_); k += 1
+        for t in range(4):
+            for s_ in range(nCP):
+                out[hc, k] = _frag(W_res, hc * 4 + t, s_); k += 1
+        for t in range(4):
+            for o in range(n_ot):
+                out[hc, k] = _frag(W_c, o, hc * 4 + t); k += 1
+    return out
+
+
 def _check_odd(ks):
     for kh, kw in ks:
         if kh % 2 == 0 or kw % 2 == 0 or kh < 1 or kw < 1:
@@ -159,6 +189,14 @@ def pack_inception(
                 raise ValueError("2.res_proj missing although d_ff != d_model")
             plan.res2 = 0
             plan.w_c2, plan.b_c2 = blob.add(W_in2), blob.add(b_in2)
+        Wc = np.concatenate([W_in2, Wr2], 0) if plan.res2 else W_in2
+        Wr1 = None
+        if plan.res1:
+            Wr1 = np.zeros((FP, CP)); Wr1[:F, :C] = sd["0.res_proj.weight"][:, :, 0, 0]
+        nKM, nCP, n_ot = CA // 16, (CP // 16 if plan.res1 else 0), Wc.shape[0] // 16
+        cf = _pack_cfrag(W_out1, Wr1, Wc, FP, nKM, nCP, n_ot)
+        plan.w_cfrag = blob.add(cf)
+        plan.cfrag_per_chunk, plan.n_hchunks = 4 * (nKM + nCP + n_ot), cf.shape[0]
     else:
         plan.mode = 1
         plan.MP, plan.nbr = 0, 1
@@ -187,6 +225,15 @@ def pack_inception(
         plan.res1, plan.w_res1, plan.b_res1 = res("0", C, F, CP, FP)
         plan.w_conv2[0], plan.b_conv2 = blob.add(c2), blob.add(bc2)
         plan.res2, plan.w_res2, plan.b_res2 = res("2", F, C, FP, CP)
+        Wr1 = Wr2 = None
+        if plan.res1:
+            Wr1 = np.zeros((FP, CP)); Wr1[:F, :C] = sd["0.res_proj.weight"][:, :, 0, 0]
+        if plan.res2:
+            Wr2 = np.zeros((CP, FP)); Wr2[:C, :F] = sd["2.res_proj.weight"][:, :, 0, 0]
+        nCP, n_ot = (CP // 16 if plan.res1 else 0), (CP // 16 if plan.res2 else 0)
+        cf = _pack_cfrag(None, Wr1, Wr2, FP, 0, nCP, n_ot)
+        plan.w_cfrag = blob.add(cf)
+        plan.cfrag_per_chunk, plan.n_hchunks = 4 * (nCP + n_ot), cf.shape[0]
     out = blob.finish()
     plan.total_floats = out.size
     return out, plan

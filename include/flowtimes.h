@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTN_ABI_VERSION 1
+#define FTN_ABI_VERSION 2
 #define FTN_KMAX 16      /* max period candidates / groups per block call        */
 #define FTN_MAXBR 8      /* max kernels in kernel_set                             */
 
@@ -78,6 +78,12 @@ typedef struct FtnPlan {
   int64_t w_res2, b_res2; /* [CP][FP], [CP]                                                 */
   /* stage-C output projection = rows [w_in2 ; w_res2] stacked: [(nbr*MP + CP)][FP]        */
   int64_t w_c2, b_c2;
+  /* the same stage-C matrices as lane-linear MFMA fragments, grouped per 64-channel
+   * hidden chunk: [chunk][ w_out1: 4 tiles x KM/16 | w_res1: 4 x CP/16 | w_c2: 4 x n_ot ][lane][4]
+   * (rows/cols beyond FP are zero fragments) */
+  int64_t w_cfrag;
+  int32_t cfrag_per_chunk;  /* fragments (of 256 floats) per hidden chunk */
+  int32_t n_hchunks;        /* ceil(FP / 64)                               */
   int64_t total_floats;
 } FtnPlan;
 

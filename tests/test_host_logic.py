@@ -32,13 +32,13 @@ def test_library_exports_every_declared_symbol(ftn):
     assert declared == set(ftn.lib.EXPORTS), declared ^ set(ftn.lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ftn_abi_version() == 1
+    assert lib.ftn_abi_version() == 2
 
 
 def test_struct_sizes_match_header(ftn):
-    # FtnDesc: 4 + 6*16 + 17 + 4*16 + 17 ints ; FtnPlan: 26 ints + 33 int64
+    # FtnDesc: 4 + 6*16 + 17 + 4*16 + 17 ints ; FtnPlan: 26 ints + 33 int64 + 2 ints + 1 int64
     assert ctypes.sizeof(ftn.lib.FtnDesc) == 4 * (4 + 6 * 16 + 17 + 4 * 16 + 17)
-    assert ctypes.sizeof(ftn.lib.FtnPlan) == 4 * 26 + 8 * 33
+    assert ctypes.sizeof(ftn.lib.FtnPlan) == 4 * 26 + 8 * 33 + 4 * 2 + 8
 
 
 @pytest.mark.parametrize("periods,L", [([24, 168, 7, 24, 0, 500], 336), ([4, 4, 8, 4], 25), ([47, 24, 2], 48),
@@ -78,6 +78,54 @@ def test_packed_weights_reproduce_reference(name, manifest, golden, ftn):
     w = orc.group_weights(amps, grp.mapping, len(grp.periods)).numpy()
     y = emu.emulate(g["x"], blob, plan, grp.periods, w)
     np.testing.assert_allclose(y, g["y"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("hyper,C", [("pipeline", 16), ("pipeline", 24), ("rect", 16), ("minimal", 16), ("wide1", 8)])
+def test_stage_c_fragments_match_row_major(hyper, C, ftn):
+    """FtnPlan.w_cfrag must hold exactly the row-major stage-C matrices, re-laid as lane-linear
+    fragments per 64-channel hidden chunk (what k_mlp stages into LDS)."""
+    h = HYP[hyper]
+    d_ff = C if h["d_ff_mult"] is None else C * h["d_ff_mult"]
+    ks = [tuple(k) for k in h["kernel_set"]]
+    sd = ftn.synth.make_inception_params(C, d_ff, ks, h["ratio"], 5)
+    blob, plan = ftn.pack.pack_inception(sd, C, d_ff, ks, h["ratio"], h["act"])
+    CP, FP = plan.CP, plan.FP
+    CA = plan.nbr * plan.MP if plan.mode == 0 else 0
+    nKM = CA // 16 if plan.mode == 0 else 0
+    nCP = CP // 16 if plan.res1 else 0
+    rows_c = (CA + (CP if plan.res2 else 0)) if plan.mode == 0 else (CP if plan.res2 else 0)
+    n_ot = rows_c // 16
+    assert plan.cfrag_per_chunk == 4 * (nKM + nCP + n_ot) and plan.n_hchunks == (FP + 63) // 64
+    cf = blob[plan.w_cfrag: plan.w_cfrag + plan.n_hchunks * max(plan.cfrag_per_chunk, 1) * 256]
+    cf = cf.reshape(plan.n_hchunks, max(plan.cfrag_per_chunk, 1), 4, 16, 4)          # [hc][frag][q][j][e]
+
+    def unfrag(fr):                                                                    # -> [16 rows j][16 cols 4q+e]
+        return fr.transpose(1, 0, 2).reshape(16, 16)
+
+    def block(W, R, S):
+        out = np.zeros((16, 16), np.float32)
+        if W is not None and 16 * R < W.shape[0] and 16 * S < W.shape[1]:
+            out[:] = W[16 * R:16 * R + 16, 16 * S:16 * S + 16]
+        return out
+
+    Wo = emu._mat(blob, plan.w_out1, FP, CA).astype(np.float32) if plan.mode == 0 else None
+    Wr = emu._mat(blob, plan.w_res1, FP, CP).astype(np.float32) if plan.res1 else None
+    Wc = None
+    if plan.mode == 0:
+        Wc = emu._mat(blob, plan.w_c2, rows_c, FP).astype(np.float32)
+    elif plan.res2:
+        Wc = emu._mat(blob, plan.w_res2, CP, FP).astype(np.float32)
+    for hc in range(plan.n_hchunks):
+        k = 0
+        for t in range(4):
+            for s_ in range(nKM):
+                np.testing.assert_array_equal(unfrag(cf[hc, k]), block(Wo, hc * 4 + t, s_)); k += 1
+        for t in range(4):
+            for s_ in range(nCP):
+                np.testing.assert_array_equal(unfrag(cf[hc, k]), block(Wr, hc * 4 + t, s_)); k += 1
+        for t in range(4):
+            for o in range(n_ot):
+                np.testing.assert_array_equal(unfrag(cf[hc, k]), block(Wc, o, hc * 4 + t)); k += 1
 
 
 def test_macs_per_pixel_matches_survey(ftn):
