@@ -28,7 +28,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 import __graft_entry__ as ge  # noqa: E402
 
-STAGES = ["A_pw_in(k_pw)", "B_conv1(k_conv)", "C_chain(k_mlp)", "D_conv2(k_conv)", "E_pw_out(k_pw)", "F_combine"]
+STAGES = ["A_pw_in(k_pw)", "B_conv1(k_conv)", "C_chain(k_mlp)", "D_conv2(k_conv)", "EF_out(k_out)", "-"]
 FP32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 HBM_PEAK_GBS = 8000.0
 

@@ -134,13 +134,13 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
 // Max abs error vs fp64 GELU over [-10,10]: 5.3e-7 (libm erff-based fp32: 6.8e-7).
 __device__ __forceinline__ float gelu_erf(float v) {
   const float z = fabsf(v) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp), not an IEEE divide
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
   p = fmaf(p, t, 0.254829592f);
   p *= t;
-  const float E = p * exp2f(z * z * -1.4426950408889634f);
+  const float E = p * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);  // raw v_exp_f32; underflow -> 0 is right
   const float hv = 0.5f * v;
   return v >= 0.0f ? fmaf(-hv, E, v) : hv * E;
 }

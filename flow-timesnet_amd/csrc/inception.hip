@@ -22,8 +22,7 @@
 //   B  k_conv      m  = conv_k(a_k) + b              (per branch mid -> mid, zero pad)
 //   C  k_mlp       g  = act(act(W_out1 m + b) + res1(x));  a' = W_in2 g + b;  r = res2(g) - x
 //   D  k_conv      m' = conv_k(a'_k) + b
-//   E  k_pw        o  = act(W_out2 m' + b) + r       (= delta_g, stored over r)
-//   F  k_combine   y  = x + sum_g w[b,g] * o_g[:L]
+//   E+F k_out      y  = x + sum_g w[b,g] * (act(W_out2 m'_g + b) + r_g)[:L]
 // Single-conv mode (ratio 1) replaces A by a zero-padded copy of x, B/D by one
 // merged conv with proj folded in, and E by an elementwise epilogue.
 #include "ftn_common.h"
@@ -202,8 +201,22 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
   for (int hc = 0; hc < a.n_hchunks; ++hc) {
     __syncthreads();
     {
+      // contiguous copy of this chunk's fragments; 8 independent 16-B loads per thread are in
+      // flight before the first LDS store (a load->store loop would expose the L2 latency 14x)
       const float* __restrict__ src = a.cfrag + (size_t)hc * a.cfrag_per_chunk * 256;
-      for (int i = threadIdx.x; i < nstage; i += 256) *(f4*)(wl + (size_t)i * 4) = *(const f4*)(src + (size_t)i * 4);
+      for (int i0 = threadIdx.x; i0 < nstage; i0 += 256 * 8) {
+        f4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = i0 + 256 * k;
+          v[k] = i < nstage ? *(const f4*)(src + (size_t)i * 4) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = i0 + 256 * k;
+          if (i < nstage) *(f4*)(wl + (size_t)i * 4) = v[k];
+        }
+      }
     }
     __syncthreads();
     if (!active) continue;
@@ -372,47 +385,54 @@ struct ConvArgs {
 #define LDS_PX_STRIDE 20  // 16 channels + 4 pad dwords
 #define CONV_NU 6         // 16-pixel units per wave: 4 waves x 6 x 16 = FTN_TILE_PX
 
-template <int NCO, int NU>
-__device__ __forceinline__ void conv_taps(f4 (&acc)[NCO][CONV_NU], const float* __restrict__ tile,
-                                          const float* __restrict__ wl, const int (&lbase)[CONV_NU],
-                                          const unsigned (&rmask)[CONV_NU], const unsigned (&cmask)[CONV_NU],
-                                          int kh, int kw, int RW, int zoff, int lane) {
-  const int hy = kh >> 1, hx = kw >> 1, ntaps = kh * kw;
-  f4 bf[NU], af[NCO];
-  auto loadB = [&](int dy, int dx, f4 (&dst)[NU]) {
-    const int toff = ((dy - hy) * RW + (dx - hx)) * LDS_PX_STRIDE;
+// One kernel row (fixed dy) of taps for NU units.  KW > 0: the dx loop is fully
+// unrolled (tap offsets become ds_read immediates, no per-tap address math);
+// KW == 0: runtime kw.  Row validity is folded into the column mask once per row,
+// so a tap costs one bit test + one address select per unit.
+template <int NCO, int NU, int KW>
+__device__ __forceinline__ void conv_row(f4 (&acc)[NCO][CONV_NU], const float* __restrict__ tile,
+                                         const float* __restrict__ wrow, const int (&rowaddr)[NU],
+                                         const unsigned (&cmv)[NU], int kw, int zoff) {
+  const int n = KW > 0 ? KW : kw;
+#pragma unroll
+  for (int dx = 0; dx < n; ++dx) {
+    f4 bf[NU], af[NCO];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const bool v = ((rmask[u] >> dy) & (cmask[u] >> dx) & 1u) != 0u;
-      dst[u] = *(const f4*)(tile + (v ? lbase[u] + toff : zoff));
+      const bool v = ((cmv[u] >> dx) & 1u) != 0u;
+      bf[u] = *(const f4*)(tile + (v ? rowaddr[u] + dx * LDS_PX_STRIDE : zoff));
     }
-  };
-  auto loadA = [&](int tap, f4 (&dst)[NCO]) {
 #pragma unroll
-    for (int o = 0; o < NCO; ++o) dst[o] = *(const f4*)(wl + (tap * NCO + o) * 256 + lane * 4);
-  };
-  loadB(0, 0, bf);
-  loadA(0, af);
-  int dy = 0, dx = 0;
-  for (int tap = 0; tap < ntaps; ++tap) {
-    int ndx = dx + 1, ndy = dy;
-    if (ndx == kw) { ndx = 0; ++ndy; }
-    const int ntap = tap + 1 < ntaps ? tap + 1 : tap;
-    if (ndy == kh) { ndy = dy; ndx = dx; }
-    f4 bn[NU], an[NCO];
-    loadB(ndy, ndx, bn);
-    loadA(ntap, an);
+    for (int o = 0; o < NCO; ++o) af[o] = *(const f4*)(wrow + (dx * NCO + o) * 256);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int o = 0; o < NCO; ++o)
 #pragma unroll
         for (int u = 0; u < NU; ++u) acc[o][u] = mfma16(af[o][e], bf[u][e], acc[o][u]);
+  }
+}
+
+template <int NCO, int NU>
+__device__ __forceinline__ void conv_taps(f4 (&acc)[NCO][CONV_NU], const float* __restrict__ tile,
+                                          const float* __restrict__ wl, const int (&lbase)[CONV_NU],
+                                          const unsigned (&rmask)[CONV_NU], const unsigned (&cmask)[CONV_NU],
+                                          int kh, int kw, int RW, int zoff, int lane) {
+  const int hy = kh >> 1, hx = kw >> 1;
+  for (int dy = 0; dy < kh; ++dy) {
+    int rowaddr[NU];
+    unsigned cmv[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) bf[u] = bn[u];
-#pragma unroll
-    for (int o = 0; o < NCO; ++o) af[o] = an[o];
-    dy = ndy; dx = ndx;
+    for (int u = 0; u < NU; ++u) {
+      rowaddr[u] = lbase[u] + ((dy - hy) * RW - hx) * LDS_PX_STRIDE;
+      cmv[u] = ((rmask[u] >> dy) & 1u) ? cmask[u] : 0u;
+    }
+    const float* __restrict__ wrow = wl + (size_t)dy * kw * NCO * 256 + lane * 4;
+    if (kw == 7) conv_row<NCO, NU, 7>(acc, tile, wrow, rowaddr, cmv, kw, zoff);
+    else if (kw == 5) conv_row<NCO, NU, 5>(acc, tile, wrow, rowaddr, cmv, kw, zoff);
+    else if (kw == 3) conv_row<NCO, NU, 3>(acc, tile, wrow, rowaddr, cmv, kw, zoff);
+    else if (kw == 1) conv_row<NCO, NU, 1>(acc, tile, wrow, rowaddr, cmv, kw, zoff);
+    else conv_row<NCO, NU, 0>(acc, tile, wrow, rowaddr, cmv, kw, zoff);
   }
 }
 
@@ -448,7 +468,8 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   const float* __restrict__ in = a.in + nimg * a.INC + br * a.in_stride_br;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int npx = th * tw, nunits = (npx + 15) >> 4;
-  const int nu = nunits > wave ? (nunits - wave + 3) >> 2 : 0;   // units of this wave: wave, wave+4, ...
+  const int wrot = (wave + b) & 3;                                 // rotate so co-resident workgroups balance the SIMDs
+  const int nu = nunits > wrot ? (nunits - wrot + 3) >> 2 : 0;   // units of this wave: wrot, wrot+4, ...
   const int nco_tot = a.cout >> 4, co0 = chunk * NCO;
   const int ncc = a.cin >> 4, ntaps = kh * kw;
 
@@ -457,7 +478,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   bool pok[CONV_NU];
 #pragma unroll
   for (int u = 0; u < CONV_NU; ++u) {
-    int idx = (wave + 4 * u) * 16 + j;
+    int idx = (wrot + 4 * u) * 16 + j;
     pok[u] = idx < npx;
     if (!pok[u]) idx = 0;
     const int r = idx / tw, c = idx - r * tw;
@@ -484,19 +505,39 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   const int nwst = ntaps * NCO * 64;
   for (int cc = 0; cc < ncc; ++cc) {
     if (cc > 0) __syncthreads();
-    for (int s = threadIdx.x; s < nstage; s += 256) {
-      const int sp = s >> 2, qq = s & 3;
-      const int rr = sp / RW, cx = sp - rr * RW;
-      *(f4*)(tile + sp * LDS_PX_STRIDE + 4 * qq) =
-          *(const f4*)(in + (size_t)((R0 + rr) * p + C0 + cx) * a.INC + 16 * cc + 4 * qq);
+    // region and weight fragments: 6 / 8 independent 16-B loads per thread in flight per batch
+    for (int s0 = threadIdx.x; s0 < nstage; s0 += 256 * 6) {
+      f4 v[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int s = s0 + 256 * k;
+        const int sp = s >> 2, qq = s & 3;
+        const int rr = sp / RW, cx = sp - rr * RW;
+        v[k] = s < nstage ? *(const f4*)(in + (size_t)((R0 + rr) * p + C0 + cx) * a.INC + 16 * cc + 4 * qq)
+                          : f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int s = s0 + 256 * k;
+        if (s < nstage) *(f4*)(tile + (s >> 2) * LDS_PX_STRIDE + 4 * (s & 3)) = v[k];
+      }
     }
-    for (int s = threadIdx.x; s < nwst; s += 256) {
-      const int tap = s / (NCO * 64), rem = s - tap * (NCO * 64);
-      const int o = rem >> 6;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (co0 + o < nco_tot)
-        v = *(const f4*)(Wb + ((size_t)(tap * ncc + cc) * nco_tot + co0 + o) * 256 + (rem & 63) * 4);
-      *(f4*)(wl + (size_t)s * 4) = v;
+    for (int s0 = threadIdx.x; s0 < nwst; s0 += 256 * 8) {
+      f4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int s = s0 + 256 * k;
+        const int tap = s / (NCO * 64), rem = s - tap * (NCO * 64);
+        const int o = rem >> 6;
+        v[k] = (s < nwst && co0 + o < nco_tot)
+                   ? *(const f4*)(Wb + ((size_t)(tap * ncc + cc) * nco_tot + co0 + o) * 256 + (rem & 63) * 4)
+                   : f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int s = s0 + 256 * k;
+        if (s < nwst) *(f4*)(wl + (size_t)s * 4) = v[k];
+      }
     }
     __syncthreads();
     switch (nu) {
@@ -534,34 +575,122 @@ __global__ void k_embed(const float* __restrict__ x, float* __restrict__ out, co
   }
 }
 
-// single-conv mode, stage E: R = act(m') + R
-template <int ACT>
-__global__ void k_final_ident(const float* __restrict__ m, float* __restrict__ R, const FtnDesc* __restrict__ d,
-                              int B, int CP) {
-  const long long total = (long long)B * d->total_px * (CP >> 2);
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const f4 v = *(const f4*)(m + e * 4);
-    const f4 r = *(const f4*)(R + e * 4);
-    *(f4*)(R + e * 4) = act4<ACT>(v) + r;
-  }
-}
+// stages E + F fused:  y = x + sum_g w[b,g] * ( act(W_out2 m'_g + b) + r_g )[:L]
+// (reference :1063-1069 delta, :1075-1092 weighted sum in group order, :818 residual).
+// One wave owns 2 units of 16 consecutive (b,t) positions and walks the groups in
+// ascending order (same summation order as the reference; deterministic, no
+// atomics); the tail pixels t >= L of every grid are never touched.  HBM/L2-bound:
+// reads m' and r once, x once, writes y once.
+struct OutArgs {
+  const float* x;
+  float* y;
+  const float* m;        // [N][KM] conv output of block 2
+  const float* R;        // [N][CP]
+  const float* W;        // w_out2 [CP][KM] row-major (IDENT: unused, KM == CP)
+  const float* bias;
+  const float* wts;      // [B][FTN_KMAX]
+  const FtnDesc* desc;
+  int B, L, C, CP, KM;
+};
 
-// stage F: y = x + sum_g w[b,g] * delta_g[:L]          (:1075-1092, :818)
-__global__ void k_combine(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ R,
-                          const float* __restrict__ wts, const FtnDesc* __restrict__ d, int B, int L, int C, int CP) {
-  const int G = d->n_groups;
-  const long long total = (long long)B * L * C;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % C);
-    const long long bt = e / C;
-    const int t = (int)(bt % L), b = (int)(bt / L);
-    float comb = 0.f;
+template <int ACT, bool XVEC, bool IDENT>
+__global__ __launch_bounds__(256) void k_out(OutArgs a) {
+  constexpr int NPX = 2;
+  const FtnDesc* __restrict__ d = a.desc;
+  const int total = a.B * a.L;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * (16 * NPX);
+  if (n0 >= total) return;
+  int bb[NPX], tt[NPX];
+  bool ok[NPX];
+#pragma unroll
+  for (int u = 0; u < NPX; ++u) {
+    int n = n0 + 16 * u + j;
+    ok[u] = n < total;
+    if (!ok[u]) n = total - 1;
+    bb[u] = n / a.L;
+    tt[u] = n - bb[u] * a.L;
+  }
+  const int G = d->n_groups, KM = a.KM, CP = a.CP, n_ot = CP >> 4;
+  for (int og = 0; og < n_ot; og += 4) {
+    f4 yacc[4][NPX];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) yacc[o][u] = f4{0.f, 0.f, 0.f, 0.f};
     for (int g = 0; g < G; ++g) {
       const int P = d->g_px_off[g + 1] - d->g_px_off[g];
-      const size_t n = (size_t)B * d->g_px_off[g] + (size_t)b * P + t;
-      comb += R[n * CP + c] * wts[(size_t)b * FTN_KMAX + g];
+      size_t pn[NPX];
+      float w[NPX];
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) {
+        pn[u] = (size_t)a.B * d->g_px_off[g] + (size_t)bb[u] * P + tt[u];
+        w[u] = a.wts[(size_t)bb[u] * FTN_KMAX + g];
+      }
+      f4 z[4][NPX];
+      if (IDENT) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) {
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (og + o < n_ot) v = *(const f4*)(a.m + pn[u] * KM + 16 * (og + o) + 4 * q);
+            z[o][u] = v;
+          }
+      } else {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          f4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (og + o < n_ot) bv = *(const f4*)(a.bias + 16 * (og + o) + 4 * q);
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) z[o][u] = bv;
+        }
+        for (int s = 0; s < KM; s += 16) {
+          f4 bf[NPX];
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) bf[u] = *(const f4*)(a.m + pn[u] * KM + s + 4 * q);
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            if (og + o < n_ot) {
+              const f4 af = *(const f4*)(a.W + (size_t)(16 * (og + o) + j) * KM + s + 4 * q);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < NPX; ++u) z[o][u] = mfma16(af[e], bf[u][e], z[o][u]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        if (og + o < n_ot) {
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) {
+            const f4 r = *(const f4*)(a.R + pn[u] * CP + 16 * (og + o) + 4 * q);
+            const f4 dl = act4<ACT>(z[o][u]) + r;
+            yacc[o][u] += dl * w[u];
+          }
+        }
+      }
     }
-    y[e] = x[e] + comb;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (og + o < n_ot) {
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+          if (!ok[u]) continue;
+          const int ch = 16 * (og + o) + 4 * q;
+          const size_t e0 = ((size_t)bb[u] * a.L + tt[u]) * a.C + ch;
+          if (XVEC) {
+            if (ch < a.C) *(f4*)(a.y + e0) = *(const f4*)(a.x + e0) + yacc[o][u];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (ch + r < a.C) a.y[e0 + r] = a.x[e0 + r] + yacc[o][u][r];
+          }
+        }
+      }
+    }
   }
 }
 
@@ -772,6 +901,8 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
   worst_tiles(L, max_groups, &tiles_row);
   const int nblk_pw = (int)((Nmax + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));
   const int nblk_ew = 2048;
+  const bool yvec = ((uintptr_t)y & 15) == 0;
+  const int nblk_out = (int)(((long long)B * L + 127) / 128);
   int rc;
   prof_mark(0, st);
   if (pl->mode == 0) {
@@ -807,11 +938,13 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
     if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
     prof_mark(4, st);
-    // E: delta = act(W_out2 m' + b) + r   (in place over r)
-    PwArgs pe = {};
-    pe.x = x; pe.in = buf1; pe.W = wb + pl->w_out2; pe.bias = wb + pl->b_out2; pe.R = bufR; pe.desc = desc;
-    pe.B = B; pe.L = L; pe.C = C; pe.KIN = CA; pe.n_ot = CP / 16; pe.RC = CP;
-    if ((rc = launch_pw<ACT, false, 1>(pe, xvec, nblk_pw, st))) return rc;
+    // E+F: y = x + sum_g w (act(W_out2 m' + b) + r)
+    OutArgs oa = {};
+    oa.x = x; oa.y = y; oa.m = buf1; oa.R = bufR; oa.W = wb + pl->w_out2; oa.bias = wb + pl->b_out2; oa.wts = wts;
+    oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CA;
+    if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, false>), dim3(nblk_out), dim3(256), 0, st, oa);
+    else hipLaunchKernelGGL((k_out<ACT, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
+    FTN_CHECK_LAUNCH();
     prof_mark(5, st);
   } else {
     // A: zero-extended copy of x
@@ -844,14 +977,15 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ca.W[0] = wb + pl->w_conv2[0];
     if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
     prof_mark(4, st);
-    // E: delta = act(m') + r
-    hipLaunchKernelGGL(k_final_ident<ACT>, dim3(nblk_ew), dim3(256), 0, st, buf0, bufR, desc, B, CP);
+    // E+F: y = x + sum_g w (act(m') + r)
+    OutArgs oa = {};
+    oa.x = x; oa.y = y; oa.m = buf0; oa.R = bufR; oa.W = nullptr; oa.bias = nullptr; oa.wts = wts;
+    oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CP;
+    if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, true>), dim3(nblk_out), dim3(256), 0, st, oa);
+    else hipLaunchKernelGGL((k_out<ACT, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
     FTN_CHECK_LAUNCH();
     prof_mark(5, st);
   }
-  // F: y = x + sum_g w delta_g
-  hipLaunchKernelGGL(k_combine, dim3(nblk_ew), dim3(256), 0, st, x, y, bufR, wts, desc, B, L, C, CP);
-  FTN_CHECK_LAUNCH();
   prof_mark(6, st);
   if (g_prof.on && g_prof.calls < FTN_PROF_CALLS) ++g_prof.calls;
   return 0;

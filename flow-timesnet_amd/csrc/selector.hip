@@ -70,15 +70,23 @@ __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, i
     const int c = ct * 32 + i;
     const bool cok = c < C;
     f16v re = {0}, im = {0};
-#pragma unroll 4
-    for (int t = 0; t < L; t += 2) {
-      const int tt = t + h;
-      const bool tok = tt < L;
-      const float ac = tok ? ctab[(size_t)tt * FPAD] : 0.f;
-      const float as = tok ? stab[(size_t)tt * FPAD] : 0.f;
-      const float bv = (tok && cok) ? xb[(size_t)tt * C + c] : 0.f;
-      re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bv, re, 0, 0, 0);
-      im = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bv, im, 0, 0, 0);
+    // 8 k-steps (16 time samples) per iteration: 24 independent loads are in flight
+    // before the 16 MFMAs that consume them
+    for (int t = 0; t < L; t += 16) {
+      float ac[8], as[8], bv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int tt = t + 2 * k + h;
+        const bool tok = tt < L;
+        ac[k] = tok ? ctab[(size_t)tt * FPAD] : 0.f;
+        as[k] = tok ? stab[(size_t)tt * FPAD] : 0.f;
+        bv[k] = (tok && cok) ? xb[(size_t)tt * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[k], bv[k], re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k], bv[k], im, 0, 0, 0);
+      }
     }
     if (cok) {
 #pragma unroll
