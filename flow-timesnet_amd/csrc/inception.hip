@@ -29,6 +29,16 @@
 
 #define NPXU 4  // 16-pixel units per wave in the pointwise / conv kernels
 
+// Diagnostic cycle stamps (ftn_debug_stamps): when a buffer is registered, thread 0 of
+// every k_conv / k_mlp workgroup stores s_memtime at its phase boundaries there.  The
+// buffer is read by nothing else; production runs leave the pointer null.
+static unsigned long long* g_stamp_buf = nullptr;
+static size_t g_stamp_cap = 0;
+static int g_stamp_which = 0;  // 1: k_conv, 2: k_mlp
+__device__ __forceinline__ void stamp(unsigned long long* buf, size_t cap, size_t wg, int slot) {
+  if (buf != nullptr && threadIdx.x == 0 && (wg * 8 + slot) < cap) buf[wg * 8 + slot] = __builtin_amdgcn_s_memtime();
+}
+
 struct PwArgs {
   const float* x;        // [B][L][C] (when XIN)
   const float* in;       // [N][KIN]  (when !XIN)
@@ -167,6 +177,7 @@ struct MlpArgs {
   int n_ot;              // total output tiles (n_oa + CP/16 when res2 is a conv)
   int res2_ident;        // 1: r = g - x  (FP == CP), taken from the hidden tiles
   int n_hchunks, cfrag_per_chunk;
+  unsigned long long* dbg; size_t dbg_cap;
 };
 
 template <int ACT, bool XVEC, int NPX, int OTM, bool EXACT>
@@ -175,6 +186,7 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const FtnDesc* __restrict__ d = a.desc;
   const int N = a.B * d->total_px;
+  stamp(a.dbg, a.dbg_cap, blockIdx.x, 0);
   if ((int)(blockIdx.x * 4 * 16 * NPX) >= N) return;            // whole workgroup beyond the live pixels
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int n0 = (blockIdx.x * 4 + wave) * (16 * NPX);
@@ -219,6 +231,8 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
       }
     }
     __syncthreads();
+    if (hc == 0) stamp(a.dbg, a.dbg_cap, blockIdx.x, 1);
+    if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 2);
     if (!active) continue;
     f4 h[HT][NPX];
     // ---- z = W_out1 m + b   (or z = m)
@@ -335,6 +349,7 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
       }
     }
   }
+  stamp(a.dbg, a.dbg_cap, blockIdx.x, 3);
   if (!active) return;
   // ---- epilogue: a' tiles, then r = res2(g) - x tiles
 #pragma unroll
@@ -380,6 +395,7 @@ struct ConvArgs {
   int region_floats;     // LDS floats reserved for the staged region (+ zero slot)
   int kh[FTN_MAXBR], kw[FTN_MAXBR];
   int order[FTN_MAXBR];  // branches sorted by descending tap count (heavy workgroups first)
+  unsigned long long* dbg; size_t dbg_cap;
 };
 
 #define LDS_PX_STRIDE 20  // 16 channels + 4 pad dwords
@@ -440,8 +456,15 @@ template <int NCO>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const FtnDesc* __restrict__ d = a.desc;
-  const int bx = blockIdx.x;
-  if (bx >= d->tiles_per_row) return;   // worst-case grid, data-dependent tile count
+  const size_t wgid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  stamp(a.dbg, a.dbg_cap, wgid, 0);
+  if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) a.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+  // grid.x = max_groups (one tile per group is the common case); a workgroup walks the
+  // data-dependent tile list with that stride, so no workgroup is dispatched empty unless
+  // groups merged (interleaved empty workgroups skew the round-robin XCD placement)
+  const int tiles_total = d->tiles_per_row;
+  for (int bx = blockIdx.x; bx < tiles_total; bx += gridDim.x) {
+  if (bx != (int)blockIdx.x) __syncthreads();
   const int b = blockIdx.y;
   const int zb = blockIdx.z / a.nchunk, chunk = blockIdx.z - zb * a.nchunk;
   const int br = a.order[zb];
@@ -476,18 +499,23 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   int lbase[CONV_NU], oidx[CONV_NU];
   unsigned rmask[CONV_NU], cmask[CONV_NU];
   bool pok[CONV_NU];
+  // idx / tw by reciprocal: exact for idx < 2^20 because (idx + 0.5) / tw is never an integer
+  const float inv_tw = 1.0f / (float)tw;
+  const unsigned kmh = (1u << kh) - 1u, kmw = (1u << kw) - 1u;
 #pragma unroll
   for (int u = 0; u < CONV_NU; ++u) {
     int idx = (wrot + 4 * u) * 16 + j;
     pok[u] = idx < npx;
     if (!pok[u]) idx = 0;
-    const int r = idx / tw, c = idx - r * tw;
+    const int r = (int)(((float)idx + 0.5f) * inv_tw), c = idx - r * tw;
     const int ri = r0 + r, ci = c0 + c;
     lbase[u] = ((ri - R0) * RW + (ci - C0)) * LDS_PX_STRIDE + 4 * q;
     oidx[u] = ri * p + ci;
-    unsigned rm = 0, cm = 0;
-    for (int dy = 0; dy < kh; ++dy) { const int rr = ri + dy - hy; rm |= (rr >= 0 && rr < cycles) ? (1u << dy) : 0u; }
-    for (int dx = 0; dx < kw; ++dx) { const int cx = ci + dx - hx; cm |= (cx >= 0 && cx < p) ? (1u << dx) : 0u; }
+    // taps dy with 0 <= ri + dy - hy < cycles are the bits [lo, hi) of the row mask (same for columns)
+    const int rlo = max(0, hy - ri), rhi = min(kh, cycles + hy - ri);
+    const int clo = max(0, hx - ci), chi = min(kw, p + hx - ci);
+    const unsigned rm = (rhi > rlo) ? ((kmh >> (kh - rhi)) & (kmh << rlo)) & kmh : 0u;
+    const unsigned cm = (chi > clo) ? ((kmw >> (kw - chi)) & (kmw << clo)) & kmw : 0u;
     rmask[u] = pok[u] ? rm : 0u;
     cmask[u] = pok[u] ? cm : 0u;
   }
@@ -502,17 +530,33 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   if (threadIdx.x < 4) *(f4*)(tile + zoff + 4 * threadIdx.x) = f4{0.f, 0.f, 0.f, 0.f};
   const float* __restrict__ Wb = a.W[br];
   const int nstage = RH * RW * 4;
-  const int nwst = ntaps * NCO * 64;
+  const float inv_rw = 1.0f / (float)RW;
   for (int cc = 0; cc < ncc; ++cc) {
     if (cc > 0) __syncthreads();
-    // region and weight fragments: 6 / 8 independent 16-B loads per thread in flight per batch
+    // weight fragments: LDS-DMA (global_load_lds_dwordx4), one 1-KiB fragment per wave
+    // instruction, no VGPR round trip; all pieces of a wave are in flight together and the
+    // region loads below join the same queue, so staging costs ~one L2 latency.
+    {
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      const int npieces = ntaps * NCO;
+      for (int piece = wv; piece < npieces; piece += 4) {
+        const int tap = piece / NCO, o = piece - tap * NCO;
+        if (co0 + o < nco_tot) {
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(Wb + ((size_t)(tap * ncc + cc) * nco_tot + co0 + o) * 256 + lane * 4),
+              (__attribute__((address_space(3))) void*)(wl + (size_t)piece * 256), 16, 0, 0);
+        } else {
+          *(f4*)(wl + (size_t)piece * 256 + lane * 4) = f4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
     for (int s0 = threadIdx.x; s0 < nstage; s0 += 256 * 6) {
       f4 v[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         const int s = s0 + 256 * k;
         const int sp = s >> 2, qq = s & 3;
-        const int rr = sp / RW, cx = sp - rr * RW;
+        const int rr = (int)(((float)sp + 0.5f) * inv_rw), cx = sp - rr * RW;
         v[k] = s < nstage ? *(const f4*)(in + (size_t)((R0 + rr) * p + C0 + cx) * a.INC + 16 * cc + 4 * qq)
                           : f4{0.f, 0.f, 0.f, 0.f};
       }
@@ -522,24 +566,8 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         if (s < nstage) *(f4*)(tile + (s >> 2) * LDS_PX_STRIDE + 4 * (s & 3)) = v[k];
       }
     }
-    for (int s0 = threadIdx.x; s0 < nwst; s0 += 256 * 8) {
-      f4 v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int s = s0 + 256 * k;
-        const int tap = s / (NCO * 64), rem = s - tap * (NCO * 64);
-        const int o = rem >> 6;
-        v[k] = (s < nwst && co0 + o < nco_tot)
-                   ? *(const f4*)(Wb + ((size_t)(tap * ncc + cc) * nco_tot + co0 + o) * 256 + (rem & 63) * 4)
-                   : f4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int s = s0 + 256 * k;
-        if (s < nwst) *(f4*)(wl + (size_t)s * 4) = v[k];
-      }
-    }
     __syncthreads();
+    if (cc == 0) stamp(a.dbg, a.dbg_cap, wgid, 1);
     switch (nu) {
       case 6: conv_taps<NCO, 6>(acc, tile, wl, lbase, rmask, cmask, kh, kw, RW, zoff, lane); break;
       case 5: conv_taps<NCO, 5>(acc, tile, wl, lbase, rmask, cmask, kh, kw, RW, zoff, lane); break;
@@ -550,6 +578,11 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
       default: break;
     }
   }
+  stamp(a.dbg, a.dbg_cap, wgid, 2);
+  if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) {
+    a.dbg[wgid * 8 + 4] = (unsigned long long)(kh * kw);
+    a.dbg[wgid * 8 + 5] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // XCC_ID
+  }
   float* __restrict__ out = a.out + nimg * a.OUTC + br * a.out_stride_br;
 #pragma unroll
   for (int o = 0; o < NCO; ++o) {
@@ -559,6 +592,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         if (u < nu && pok[u]) *(f4*)(out + (size_t)oidx[u] * a.OUTC + 16 * (co0 + o) + 4 * q) = acc[o][u];
     }
   }
+  stamp(a.dbg, a.dbg_cap, wgid, 3);
+  if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) a.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+  }  // tile loop
 }
 
 // ---------------------------------------------------------------- small elementwise stages
@@ -711,6 +747,13 @@ static void prof_mark(int stage, hipStream_t st) {
   if (g_prof.on && g_prof.calls < FTN_PROF_CALLS) (void)hipEventRecord(g_prof.ev[g_prof.calls][stage], st);
 }
 
+extern "C" int ftn_debug_stamps(void* buf_dev, size_t n_u64, int which) {
+  g_stamp_buf = (unsigned long long*)buf_dev;
+  g_stamp_cap = buf_dev ? n_u64 : 0;
+  g_stamp_which = which;
+  return 0;
+}
+
 extern "C" int ftn_stage_timing(int enable) {
   if (enable && !g_prof.created) {
     for (int c = 0; c < FTN_PROF_CALLS; ++c)
@@ -819,7 +862,7 @@ static int launch_conv_t(const ConvArgs& ca, dim3 grid, size_t lds, hipStream_t 
   return 0;
 }
 
-static int launch_conv(ConvArgs& ca, int B, int L, int tiles_per_row, hipStream_t st) {
+static int launch_conv(ConvArgs& ca, int B, int L, int grid_x, hipStream_t st) {
   const int nco_tot = ca.cout / 16;
   int region_px = 1, max_taps = 1;
   for (int k = 0; k < ca.nbr; ++k) {
@@ -843,7 +886,8 @@ static int launch_conv(ConvArgs& ca, int B, int L, int tiles_per_row, hipStream_
     while (jj >= 0 && ca.kh[ca.order[jj]] * ca.kw[ca.order[jj]] < ca.kh[v] * ca.kw[v]) { ca.order[jj + 1] = ca.order[jj]; --jj; }
     ca.order[jj + 1] = v;
   }
-  dim3 grid(tiles_per_row, B, ca.nbr * ca.nchunk);
+  ca.dbg = (g_stamp_which & 1) ? g_stamp_buf : nullptr; ca.dbg_cap = g_stamp_cap;
+  dim3 grid(grid_x, B, ca.nbr * ca.nchunk);
   if (NCO == 4) return launch_conv_t<4>(ca, grid, lds, st);
   if (NCO == 2) return launch_conv_t<2>(ca, grid, lds, st);
   return launch_conv_t<1>(ca, grid, lds, st);
@@ -858,7 +902,8 @@ static int launch_pw(const PwArgs& pa, bool xvec, int nblk, hipStream_t st) {
 }
 
 template <int ACT, bool XVEC, int NPX, int OTM, bool EXACT>
-static int launch_mlp_t(const MlpArgs& ma, long long Nmax, hipStream_t st) {
+static int launch_mlp_t(MlpArgs ma, long long Nmax, hipStream_t st) {
+  ma.dbg = (g_stamp_which & 2) ? g_stamp_buf : nullptr; ma.dbg_cap = g_stamp_cap;
   const size_t lds = (size_t)ma.cfrag_per_chunk * 1024;
   if (lds > 160 * 1024) { ftn_set_error("stage C needs %zu B of LDS per hidden chunk", lds); return -1; }
   if (lds > 64 * 1024) {
@@ -918,7 +963,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CA; ca.OUTC = CA;
     ca.nbr = pl->nbr; ca.cin = pl->MP; ca.cout = pl->MP; ca.in_stride_br = pl->MP; ca.out_stride_br = pl->MP;
     for (int k = 0; k < pl->nbr; ++k) { ca.W[k] = wb + pl->w_conv1[k]; ca.kh[k] = pl->kh[k]; ca.kw[k] = pl->kw[k]; }
-    if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
+    if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(2, st);
     // C: fused pointwise chain
     MlpArgs ma = {};
@@ -936,7 +981,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // D: m' = conv(a')
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
-    if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
+    if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(4, st);
     // E+F: y = x + sum_g w (act(W_out2 m' + b) + r)
     OutArgs oa = {};
@@ -956,7 +1001,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CP; ca.OUTC = FP;
     ca.nbr = 1; ca.cin = CP; ca.cout = FP; ca.in_stride_br = 0; ca.out_stride_br = 0;
     ca.W[0] = wb + pl->w_conv1[0]; ca.kh[0] = pl->kh[0]; ca.kw[0] = pl->kw[0];
-    if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
+    if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(2, st);
     // C: g = act(act(m) + res1(x)) -> G ; r = res2(g) - x
     MlpArgs ma = {};
@@ -975,7 +1020,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // D: m' = conv_merged'(g)
     ca.in = bufG; ca.out = buf0; ca.bias = wb + pl->b_conv2; ca.INC = FP; ca.OUTC = CP; ca.cin = FP; ca.cout = CP;
     ca.W[0] = wb + pl->w_conv2[0];
-    if ((rc = launch_conv(ca, B, L, tiles_row, st))) return rc;
+    if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(4, st);
     // E+F: y = x + sum_g w (act(m') + r)
     OutArgs oa = {};

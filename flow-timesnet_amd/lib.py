@@ -82,6 +82,7 @@ _SIGNATURES = {
     "ftn_lrtc_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "ftn_stage_timing": (C.c_int, [C.c_int]),
     "ftn_stage_times": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
+    "ftn_debug_stamps": (C.c_int, [_P, C.c_size_t, C.c_int]),
     "ftn_selftest_mfma": (C.c_int, [_P, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -140,6 +140,11 @@ int ftn_stage_timing(int enable);
  * milliseconds; synchronises on the recorded events.  nstage must be 6. */
 int ftn_stage_times(float* ms_sum_host, int nstage, int* ncalls_host);
 
+/* Diagnostic: register (or clear with NULL) a device buffer of n_u64 64-bit words; thread 0 of
+ * every following k_conv / k_mlp workgroup stores s_memtime at its phase boundaries in
+ * words [8*wg .. 8*wg+7].  The last registered conv/mlp launch wins; not for production. */
+int ftn_debug_stamps(void* buf_dev, size_t n_u64, int which /* 1: k_conv, 2: k_mlp */);
+
 /* ---- diagnostics --------------------------------------------------------------- */
 /* writes D = A(16x8, a[i][k]=i*8+k+1) * B(8x16, b[k][j]=(k+1)*100+j) via two
  * v_mfma_f32_16x16x4_f32 to out[16][16]: verifies the lane maps the kernels assume */
