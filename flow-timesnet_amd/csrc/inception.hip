@@ -159,6 +159,8 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
 // rows) straight from global/L2 with a one-step-ahead prefetch; the hidden
 // accumulators then ARE the B fragments of the output projection, which
 // accumulates across chunks in registers.  Nothing hidden-sized touches memory.
+#define MLP_HT 2   // hidden row tiles per chunk (pack.py CHUNK_TILES)
+
 struct MlpArgs {
   const float* x;
   const float* m;        // [N][KM] conv output of block 1
@@ -180,9 +182,14 @@ struct MlpArgs {
   unsigned long long* dbg; size_t dbg_cap;
 };
 
-template <int ACT, bool XVEC, int NPX, int OTM, bool EXACT>
+// PRE: the B fragments of layer 1 (m rows, <= 3 K-chunks) and of the residual (x rows, <= 4
+// K-chunks) do not depend on the hidden chunk, so they are loaded ONCE into registers and the
+// chunk loop touches no global memory besides the weight DMA.
+#define MLP_PRE_KM 3
+#define MLP_PRE_CP 4
+template <int ACT, bool XVEC, int NPX, int OTM, bool EXACT, bool PRE>
 __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
-  constexpr int HT = 4;
+  constexpr int HT = MLP_HT;
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const FtnDesc* __restrict__ d = a.desc;
   const int N = a.B * d->total_px;
@@ -191,6 +198,20 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int n0 = (blockIdx.x * 4 + wave) * (16 * NPX);
   const bool active = n0 < N;                                    // wave-uniform; idle waves still stage + sync
+  // Weight fragments reach LDS by DMA (global_load_lds_dwordx4, 1 KiB per wave instruction)
+  // into two buffers: chunk hc+1 is requested right before the output-projection MFMAs of
+  // chunk hc (the longest phase, no other memory traffic) and has landed by the barrier that
+  // ends the chunk, so staging is off the critical path.
+  const int bufsz = a.cfrag_per_chunk * 256;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_chunk = [&](int hc, int buf) {
+    const float* __restrict__ src = a.cfrag + (size_t)hc * bufsz;
+    for (int piece = wv; piece < a.cfrag_per_chunk; piece += 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 256 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(wl + (size_t)buf * bufsz + (size_t)piece * 256),
+                                       16, 0, 0);
+  };
+  dma_chunk(0, 0);                                               // lands while the pixels are decoded
   Px px[NPX];
 #pragma unroll
   for (int u = 0; u < NPX; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
@@ -198,8 +219,19 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
   const int nht = FP >> 4;
   const int nKM = a.nKM, nCP = a.nCP, n_ot = EXACT ? OTM : a.n_ot;
   const int offWr = HT * nKM, offWc = offWr + HT * nCP;
-  const float* __restrict__ wlane = wl + lane * 4;
-
+  f4 mpre[PRE ? MLP_PRE_KM : 1][NPX], xpre[PRE ? MLP_PRE_CP : 1][NPX];
+  if (PRE) {
+#pragma unroll
+    for (int s = 0; s < MLP_PRE_KM; ++s)
+#pragma unroll
+      for (int u = 0; u < NPX; ++u)
+        mpre[s][u] = s < nKM ? *(const f4*)(a.m + (size_t)px[u].n * KM + 16 * s + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < MLP_PRE_CP; ++s)
+#pragma unroll
+      for (int u = 0; u < NPX; ++u)
+        xpre[s][u] = s < nCP ? load_x4<XVEC>(px[u].xrow, 16 * s + 4 * q, a.C) : f4{0.f, 0.f, 0.f, 0.f};
+  }
   f4 oacc[OTM][NPX];
 #pragma unroll
   for (int o = 0; o < OTM; ++o) {
@@ -209,31 +241,12 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
     for (int u = 0; u < NPX; ++u) oacc[o][u] = bv;
   }
 
-  const int nstage = a.cfrag_per_chunk * 64;
+  __syncthreads();
+  stamp(a.dbg, a.dbg_cap, blockIdx.x, 1);
   for (int hc = 0; hc < a.n_hchunks; ++hc) {
-    __syncthreads();
-    {
-      // contiguous copy of this chunk's fragments; 8 independent 16-B loads per thread are in
-      // flight before the first LDS store (a load->store loop would expose the L2 latency 14x)
-      const float* __restrict__ src = a.cfrag + (size_t)hc * a.cfrag_per_chunk * 256;
-      for (int i0 = threadIdx.x; i0 < nstage; i0 += 256 * 8) {
-        f4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int i = i0 + 256 * k;
-          v[k] = i < nstage ? *(const f4*)(src + (size_t)i * 4) : f4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int i = i0 + 256 * k;
-          if (i < nstage) *(f4*)(wl + (size_t)i * 4) = v[k];
-        }
-      }
-    }
-    __syncthreads();
-    if (hc == 0) stamp(a.dbg, a.dbg_cap, blockIdx.x, 1);
+    const float* __restrict__ wlane = wl + (size_t)(hc & 1) * bufsz + lane * 4;
     if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 2);
-    if (!active) continue;
+    if (active) {
     f4 h[HT][NPX];
     // ---- z = W_out1 m + b   (or z = m)
     if (nKM > 0) {
@@ -244,24 +257,40 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
 #pragma unroll
         for (int u = 0; u < NPX; ++u) h[t][u] = bv;
       }
-      f4 bcur[NPX];
+      if (PRE) {
 #pragma unroll
-      for (int u = 0; u < NPX; ++u) bcur[u] = *(const f4*)(a.m + (size_t)px[u].n * KM + 4 * q);
-      for (int s = 0; s < nKM; ++s) {
-        const int sn = s + 1 < nKM ? s + 1 : s;
-        f4 bnxt[NPX];
+        for (int s = 0; s < MLP_PRE_KM; ++s) {
+          if (s < nKM) {
 #pragma unroll
-        for (int u = 0; u < NPX; ++u) bnxt[u] = *(const f4*)(a.m + (size_t)px[u].n * KM + 16 * sn + 4 * q);
+            for (int t = 0; t < HT; ++t) {
+              const f4 af = *(const f4*)(wlane + (t * nKM + s) * 256);
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          const f4 af = *(const f4*)(wlane + (t * nKM + s) * 256);
+              for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bcur[u][e], h[t][u]);
+                for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], mpre[s][u][e], h[t][u]);
+            }
+          }
         }
+      } else {
+        f4 bcur[NPX];
 #pragma unroll
-        for (int u = 0; u < NPX; ++u) bcur[u] = bnxt[u];
+        for (int u = 0; u < NPX; ++u) bcur[u] = *(const f4*)(a.m + (size_t)px[u].n * KM + 4 * q);
+        for (int s = 0; s < nKM; ++s) {
+          const int sn = s + 1 < nKM ? s + 1 : s;
+          f4 bnxt[NPX];
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) bnxt[u] = *(const f4*)(a.m + (size_t)px[u].n * KM + 16 * sn + 4 * q);
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            const f4 af = *(const f4*)(wlane + (t * nKM + s) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bcur[u][e], h[t][u]);
+          }
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) bcur[u] = bnxt[u];
+        }
       }
     } else {
 #pragma unroll
@@ -287,24 +316,40 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
           for (int u = 0; u < NPX; ++u) h[t][u] += bv;
         }
       }
-      f4 bcur[NPX];
+      if (PRE) {
 #pragma unroll
-      for (int u = 0; u < NPX; ++u) bcur[u] = load_x4<XVEC>(px[u].xrow, 4 * q, a.C);
-      for (int s = 0; s < nCP; ++s) {
-        const int sn = s + 1 < nCP ? s + 1 : s;
-        f4 bnxt[NPX];
+        for (int s = 0; s < MLP_PRE_CP; ++s) {
+          if (s < nCP) {
 #pragma unroll
-        for (int u = 0; u < NPX; ++u) bnxt[u] = load_x4<XVEC>(px[u].xrow, 16 * sn + 4 * q, a.C);
+            for (int t = 0; t < HT; ++t) {
+              const f4 af = *(const f4*)(wlane + (offWr + t * nCP + s) * 256);
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-          const f4 af = *(const f4*)(wlane + (offWr + t * nCP + s) * 256);
+              for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bcur[u][e], h[t][u]);
+                for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], xpre[s][u][e], h[t][u]);
+            }
+          }
         }
+      } else {
+        f4 bcur[NPX];
 #pragma unroll
-        for (int u = 0; u < NPX; ++u) bcur[u] = bnxt[u];
+        for (int u = 0; u < NPX; ++u) bcur[u] = load_x4<XVEC>(px[u].xrow, 4 * q, a.C);
+        for (int s = 0; s < nCP; ++s) {
+          const int sn = s + 1 < nCP ? s + 1 : s;
+          f4 bnxt[NPX];
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) bnxt[u] = load_x4<XVEC>(px[u].xrow, 16 * sn + 4 * q, a.C);
+#pragma unroll
+          for (int t = 0; t < HT; ++t) {
+            const f4 af = *(const f4*)(wlane + (offWr + t * nCP + s) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int u = 0; u < NPX; ++u) h[t][u] = mfma16(af[e], bcur[u][e], h[t][u]);
+          }
+#pragma unroll
+          for (int u = 0; u < NPX; ++u) bcur[u] = bnxt[u];
+        }
       }
     } else {
 #pragma unroll
@@ -334,7 +379,9 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
         }
       }
     }
-    // ---- output projection: the hidden accumulators ARE the B fragments
+    // ---- request the next chunk's fragments, then the output projection: the hidden
+    //      accumulators ARE the B fragments
+    if (hc + 1 < a.n_hchunks) dma_chunk(hc + 1, (hc + 1) & 1);
 #pragma unroll
     for (int t = 0; t < HT; ++t) {
 #pragma unroll
@@ -348,6 +395,10 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
         }
       }
     }
+    } else if (hc + 1 < a.n_hchunks) {
+      dma_chunk(hc + 1, (hc + 1) & 1);
+    }
+    __syncthreads();   // everyone is done with this buffer and (vmcnt(0)) the next one has landed
   }
   stamp(a.dbg, a.dbg_cap, blockIdx.x, 3);
   if (!active) return;
@@ -901,29 +952,33 @@ static int launch_pw(const PwArgs& pa, bool xvec, int nblk, hipStream_t st) {
   return 0;
 }
 
-template <int ACT, bool XVEC, int NPX, int OTM, bool EXACT>
+template <int ACT, bool XVEC, int NPX, int OTM, bool EXACT, bool PRE>
 static int launch_mlp_t(MlpArgs ma, long long Nmax, hipStream_t st) {
   ma.dbg = (g_stamp_which & 2) ? g_stamp_buf : nullptr; ma.dbg_cap = g_stamp_cap;
-  const size_t lds = (size_t)ma.cfrag_per_chunk * 1024;
-  if (lds > 160 * 1024) { ftn_set_error("stage C needs %zu B of LDS per hidden chunk", lds); return -1; }
+  const size_t lds = (size_t)ma.cfrag_per_chunk * 1024 * 2;   // double-buffered
+  if (lds > 160 * 1024) { ftn_set_error("stage C needs %zu B of LDS for two hidden chunks", lds); return -1; }
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<ACT, XVEC, NPX, OTM, EXACT>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp<ACT, XVEC, NPX, OTM, EXACT, PRE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp): %s", hipGetErrorString(e)); return (int)e; }
   }
   const int per = 16 * NPX * 4;
   const int nblk = (int)((Nmax + per - 1) / per);
-  hipLaunchKernelGGL((k_mlp<ACT, XVEC, NPX, OTM, EXACT>), dim3(nblk), dim3(256), lds, st, ma);
+  hipLaunchKernelGGL((k_mlp<ACT, XVEC, NPX, OTM, EXACT, PRE>), dim3(nblk), dim3(256), lds, st, ma);
   FTN_CHECK_LAUNCH();
   return 0;
 }
 
 template <int ACT, bool XVEC>
 static int launch_mlp_x(const MlpArgs& ma, long long Nmax, hipStream_t st) {
-  if (ma.n_ot == 7) return launch_mlp_t<ACT, XVEC, 3, 7, true>(ma, Nmax, st);     // d_model 64, mid 16, 3 kernels
-  if (ma.n_ot <= 8) return launch_mlp_t<ACT, XVEC, 3, 8, false>(ma, Nmax, st);
-  if (ma.n_ot == 14) return launch_mlp_t<ACT, XVEC, 2, 14, true>(ma, Nmax, st);   // d_model 128, mid 32, 3 kernels
-  return launch_mlp_t<ACT, XVEC, 2, 16, false>(ma, Nmax, st);
+  const bool pre = ma.nKM <= MLP_PRE_KM && ma.nCP <= MLP_PRE_CP;
+  if (ma.n_ot == 7 && pre) return launch_mlp_t<ACT, XVEC, 3, 7, true, true>(ma, Nmax, st);   // d_model 64, mid 16, 3 kernels
+  if (ma.n_ot <= 8) {
+    if (pre) return launch_mlp_t<ACT, XVEC, 3, 8, false, true>(ma, Nmax, st);
+    return launch_mlp_t<ACT, XVEC, 3, 8, false, false>(ma, Nmax, st);
+  }
+  if (ma.n_ot == 14) return launch_mlp_t<ACT, XVEC, 2, 14, true, false>(ma, Nmax, st);        // d_model 128, mid 32, 3 kernels
+  return launch_mlp_t<ACT, XVEC, 2, 16, false, false>(ma, Nmax, st);
 }
 
 template <int ACT>
@@ -975,7 +1030,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ma.n_hchunks = pl->n_hchunks; ma.cfrag_per_chunk = pl->cfrag_per_chunk;
     ma.n_oa = CA / 16; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = ma.n_oa + (pl->res2 ? CP / 16 : 0);
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model/mid too large for v1", ma.n_ot); return -1; }
-    if (ma.cfrag_per_chunk != 4 * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
+    if (ma.cfrag_per_chunk != MLP_HT * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
     if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
     prof_mark(3, st);
     // D: m' = conv(a')
@@ -1014,7 +1069,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ma.n_hchunks = pl->n_hchunks; ma.cfrag_per_chunk = pl->cfrag_per_chunk;
     ma.n_oa = 0; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = pl->res2 ? CP / 16 : 0;
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model too large for v1", ma.n_ot); return -1; }
-    if (ma.cfrag_per_chunk != 4 * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
+    if (ma.cfrag_per_chunk != MLP_HT * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
     if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
     prof_mark(3, st);
     // D: m' = conv_merged'(g)

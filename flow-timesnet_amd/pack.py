@@ -76,22 +76,26 @@ def _frag(W: np.ndarray, R: int, S: int) -> np.ndarray:
     return blk.reshape(16, 4, 4).transpose(1, 0, 2).reshape(-1)
 
 
+CHUNK_TILES = 2   # hidden row tiles (of 16 channels) per stage-C chunk; must match HT in csrc/inception.hip
+
+
 def _pack_cfrag(W_out, W_res, W_c, FP: int, nKM: int, nCP: int, n_ot: int) -> np.ndarray:
-    """Stage-C fragments grouped per 64-channel hidden chunk (see FtnPlan.w_cfrag)."""
-    nch = (FP + 63) // 64
-    per = 4 * (nKM + nCP + n_ot)
+    """Stage-C fragments grouped per 32-channel hidden chunk (see FtnPlan.w_cfrag)."""
+    HT = CHUNK_TILES
+    nch = (FP + 16 * HT - 1) // (16 * HT)
+    per = HT * (nKM + nCP + n_ot)
     out = np.zeros((nch, max(per, 1), 256))
     for hc in range(nch):
         k = 0
-        for t in range(4):
+        for t in range(HT):
             for s_ in range(nKM):
-                out[hc, k] = _frag(W_out, hc * 4 + t, s_); k += 1
-        for t in range(4):
+                out[hc, k] = _frag(W_out, hc * HT + t, s_); k += 1
+        for t in range(HT):
             for s_ in range(nCP):
-                out[hc, k] = _frag(W_res, hc * 4 + t, s_); k += 1
-        for t in range(4):
+                out[hc, k] = _frag(W_res, hc * HT + t, s_); k += 1
+        for t in range(HT):
             for o in range(n_ot):
-                out[hc, k] = _frag(W_c, o, hc * 4 + t); k += 1
+                out[hc, k] = _frag(W_c, o, hc * HT + t); k += 1
     return out
 
 
@@ -196,7 +200,7 @@ def pack_inception(
         nKM, nCP, n_ot = CA // 16, (CP // 16 if plan.res1 else 0), Wc.shape[0] // 16
         cf = _pack_cfrag(W_out1, Wr1, Wc, FP, nKM, nCP, n_ot)
         plan.w_cfrag = blob.add(cf)
-        plan.cfrag_per_chunk, plan.n_hchunks = 4 * (nKM + nCP + n_ot), cf.shape[0]
+        plan.cfrag_per_chunk, plan.n_hchunks = CHUNK_TILES * (nKM + nCP + n_ot), cf.shape[0]
     else:
         plan.mode = 1
         plan.MP, plan.nbr = 0, 1
@@ -233,7 +237,7 @@ def pack_inception(
         nCP, n_ot = (CP // 16 if plan.res1 else 0), (CP // 16 if plan.res2 else 0)
         cf = _pack_cfrag(None, Wr1, Wr2, FP, 0, nCP, n_ot)
         plan.w_cfrag = blob.add(cf)
-        plan.cfrag_per_chunk, plan.n_hchunks = 4 * (nCP + n_ot), cf.shape[0]
+        plan.cfrag_per_chunk, plan.n_hchunks = CHUNK_TILES * (nCP + n_ot), cf.shape[0]
     out = blob.finish()
     plan.total_floats = out.size
     return out, plan

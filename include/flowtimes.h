@@ -78,12 +78,12 @@ typedef struct FtnPlan {
   int64_t w_res2, b_res2; /* [CP][FP], [CP]                                                 */
   /* stage-C output projection = rows [w_in2 ; w_res2] stacked: [(nbr*MP + CP)][FP]        */
   int64_t w_c2, b_c2;
-  /* the same stage-C matrices as lane-linear MFMA fragments, grouped per 64-channel
-   * hidden chunk: [chunk][ w_out1: 4 tiles x KM/16 | w_res1: 4 x CP/16 | w_c2: 4 x n_ot ][lane][4]
+  /* the same stage-C matrices as lane-linear MFMA fragments, grouped per 32-channel
+   * hidden chunk: [chunk][ w_out1: 2 tiles x KM/16 | w_res1: 2 x CP/16 | w_c2: 2 x n_ot ][lane][4]
    * (rows/cols beyond FP are zero fragments) */
   int64_t w_cfrag;
   int32_t cfrag_per_chunk;  /* fragments (of 256 floats) per hidden chunk */
-  int32_t n_hchunks;        /* ceil(FP / 64)                               */
+  int32_t n_hchunks;        /* ceil(FP / 32)                               */
   int64_t total_floats;
 } FtnPlan;
 

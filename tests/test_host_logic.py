@@ -95,7 +95,8 @@ def test_stage_c_fragments_match_row_major(hyper, C, ftn):
     nCP = CP // 16 if plan.res1 else 0
     rows_c = (CA + (CP if plan.res2 else 0)) if plan.mode == 0 else (CP if plan.res2 else 0)
     n_ot = rows_c // 16
-    assert plan.cfrag_per_chunk == 4 * (nKM + nCP + n_ot) and plan.n_hchunks == (FP + 63) // 64
+    HT = ftn.pack.CHUNK_TILES
+    assert plan.cfrag_per_chunk == HT * (nKM + nCP + n_ot) and plan.n_hchunks == (FP + 16 * HT - 1) // (16 * HT)
     cf = blob[plan.w_cfrag: plan.w_cfrag + plan.n_hchunks * max(plan.cfrag_per_chunk, 1) * 256]
     cf = cf.reshape(plan.n_hchunks, max(plan.cfrag_per_chunk, 1), 4, 16, 4)          # [hc][frag][q][j][e]
 
@@ -117,15 +118,15 @@ def test_stage_c_fragments_match_row_major(hyper, C, ftn):
         Wc = emu._mat(blob, plan.w_res2, CP, FP).astype(np.float32)
     for hc in range(plan.n_hchunks):
         k = 0
-        for t in range(4):
+        for t in range(HT):
             for s_ in range(nKM):
-                np.testing.assert_array_equal(unfrag(cf[hc, k]), block(Wo, hc * 4 + t, s_)); k += 1
-        for t in range(4):
+                np.testing.assert_array_equal(unfrag(cf[hc, k]), block(Wo, hc * HT + t, s_)); k += 1
+        for t in range(HT):
             for s_ in range(nCP):
-                np.testing.assert_array_equal(unfrag(cf[hc, k]), block(Wr, hc * 4 + t, s_)); k += 1
-        for t in range(4):
+                np.testing.assert_array_equal(unfrag(cf[hc, k]), block(Wr, hc * HT + t, s_)); k += 1
+        for t in range(HT):
             for o in range(n_ot):
-                np.testing.assert_array_equal(unfrag(cf[hc, k]), block(Wc, o, hc * 4 + t)); k += 1
+                np.testing.assert_array_equal(unfrag(cf[hc, k]), block(Wc, o, hc * HT + t)); k += 1
 
 
 def test_macs_per_pixel_matches_survey(ftn):

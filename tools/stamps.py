@@ -36,12 +36,12 @@ with torch.inference_mode():
     lib.ftn_debug_stamps(None, 0, 0)
 s = buf.cpu().numpy().reshape(-1, 8)
 # both conv launches and the mlp launch write the same buffer: conv D overwrites conv B; mlp uses blockIdx.x ids
-allw = s[s[:, 6] > 0]
-print("dispatched workgroups", len(allw), "first start .. last start (us)", 0.0, (allw[:, 6].max() - allw[:, 6].min()) / 100.0)
+allw = s[s[:, 6] > 0] if (s[:, 6] > 0).any() else s[s[:, 0] > 0]
+print("dispatched workgroups", len(allw))
 live = s[:, 3] > 0
 s = s[live].astype(np.float64)
 t0 = s[:, 0].min()
-print("live workgroups", len(s), "realtime span us", (s[:, 7].max() - s[:, 6].min()) / 100.0)
+print("live workgroups", len(s))
 if which == "conv":
     xcc = s[:, 5].astype(int) & 15
     for xid in sorted(set(xcc)):
