@@ -680,7 +680,10 @@ struct OutArgs {
   int B, L, C, CP, KM;
 };
 
-template <int ACT, bool XVEC, bool IDENT>
+// Fast path (FAST): K <= 48 and <= 4 output tiles (d_model <= 64, nbr*mid <= 48): the 12
+// weight fragments are group-independent and live in registers; per group the wave only
+// streams its m' and r rows, with the next group's m' rows requested one group ahead.
+template <int ACT, bool XVEC, bool IDENT, bool FAST>
 __global__ __launch_bounds__(256) void k_out(OutArgs a) {
   constexpr int NPX = 2;
   const FtnDesc* __restrict__ d = a.desc;
@@ -699,6 +702,88 @@ __global__ __launch_bounds__(256) void k_out(OutArgs a) {
     tt[u] = n - bb[u] * a.L;
   }
   const int G = d->n_groups, KM = a.KM, CP = a.CP, n_ot = CP >> 4;
+  if (FAST) {
+    const int nKM = KM >> 4;
+    f4 aw[4][3], bias[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      bias[o] = o < n_ot ? *(const f4*)(a.bias + 16 * o + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        aw[o][s] = (o < n_ot && s < nKM) ? *(const f4*)(a.W + (size_t)(16 * o + j) * KM + 16 * s + 4 * q)
+                                         : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    f4 yacc[4][NPX], mc[3][NPX];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) yacc[o][u] = f4{0.f, 0.f, 0.f, 0.f};
+    auto pix = [&](int g, int u) -> size_t {
+      const int P = d->g_px_off[g + 1] - d->g_px_off[g];
+      return (size_t)a.B * d->g_px_off[g] + (size_t)bb[u] * P + tt[u];
+    };
+    auto load_m = [&](int g, f4 (&dst)[3][NPX]) {
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) {
+        const float* __restrict__ row = a.m + pix(g, u) * KM + 4 * q;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) dst[s][u] = s < nKM ? *(const f4*)(row + 16 * s) : f4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    if (G > 0) load_m(0, mc);
+    for (int g = 0; g < G; ++g) {
+      f4 rr[4][NPX], mn[3][NPX];
+      float w[NPX];
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) {
+        const float* __restrict__ row = a.R + pix(g, u) * CP + 4 * q;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) rr[o][u] = o < n_ot ? *(const f4*)(row + 16 * o) : f4{0.f, 0.f, 0.f, 0.f};
+        w[u] = a.wts[(size_t)bb[u] * FTN_KMAX + g];
+      }
+      load_m(g + 1 < G ? g + 1 : g, mn);
+      f4 z[4][NPX];
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) z[o][u] = bias[o];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int u = 0; u < NPX; ++u) z[o][u] = mfma16(aw[o][s][e], mc[s][u][e], z[o][u]);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) yacc[o][u] += (act4<ACT>(z[o][u]) + rr[o][u]) * w[u];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) mc[s][u] = mn[s][u];
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o < n_ot) {
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+          if (!ok[u]) continue;
+          const int ch = 16 * o + 4 * q;
+          const size_t e0 = ((size_t)bb[u] * a.L + tt[u]) * a.C + ch;
+          if (XVEC) {
+            if (ch < a.C) *(f4*)(a.y + e0) = *(const f4*)(a.x + e0) + yacc[o][u];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (ch + r < a.C) a.y[e0 + r] = a.x[e0 + r] + yacc[o][u][r];
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int og = 0; og < n_ot; og += 4) {
     f4 yacc[4][NPX];
 #pragma unroll
@@ -1042,8 +1127,11 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     OutArgs oa = {};
     oa.x = x; oa.y = y; oa.m = buf1; oa.R = bufR; oa.W = wb + pl->w_out2; oa.bias = wb + pl->b_out2; oa.wts = wts;
     oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CA;
-    if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, false>), dim3(nblk_out), dim3(256), 0, st, oa);
-    else hipLaunchKernelGGL((k_out<ACT, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
+    const bool fast = CA <= 48 && CP <= 64;
+    if (xvec && yvec && fast) hipLaunchKernelGGL((k_out<ACT, true, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
+    else if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
+    else if (fast) hipLaunchKernelGGL((k_out<ACT, false, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
+    else hipLaunchKernelGGL((k_out<ACT, false, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
     FTN_CHECK_LAUNCH();
     prof_mark(5, st);
   } else {
@@ -1081,8 +1169,8 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     OutArgs oa = {};
     oa.x = x; oa.y = y; oa.m = buf0; oa.R = bufR; oa.W = nullptr; oa.bias = nullptr; oa.wts = wts;
     oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CP;
-    if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, true>), dim3(nblk_out), dim3(256), 0, st, oa);
-    else hipLaunchKernelGGL((k_out<ACT, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
+    if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, true, false>), dim3(nblk_out), dim3(256), 0, st, oa);
+    else hipLaunchKernelGGL((k_out<ACT, false, true, false>), dim3(nblk_out), dim3(256), 0, st, oa);
     FTN_CHECK_LAUNCH();
     prof_mark(5, st);
   }

@@ -66,16 +66,29 @@ extern "C" int ftn_lrtc_basis(float* basis_dev, int L, int R, void* stream) {
   return 0;
 }
 
-#define LRTC_LT 16  // time steps per workgroup slab
+#define LRTC_LT 48  // time steps per lane-group slab (coefficients are re-read once per slab)
 
 template <int RT, bool VEC, bool ADDX>
 __global__ __launch_bounds__(256) void k_lrtc(const float* __restrict__ coeff, const float* __restrict__ basis,
                                               const float* __restrict__ scale_p, const float* __restrict__ x,
-                                              float* __restrict__ out, int L, int N, int R) {
+                                              float* __restrict__ out, int L, int N, int R, int nqb) {
+  // nqb lanes (multiple of 64) span the series quads of this block; the remaining 256/nqb
+  // lane groups take further time slabs, so narrow N still fills the workgroup.  The basis
+  // rows of the block's slabs are staged once in LDS (broadcast reads), padded to RT columns.
+  __shared__ float bs[(256 / 64) * LRTC_LT * RT];
+  const int nsl = 256 / nqb;
   const int b = blockIdx.z;
-  const int n0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  const int l0 = blockIdx.y * LRTC_LT;
-  if (n0 >= N) return;
+  const int nq = threadIdx.x % nqb, sl = threadIdx.x / nqb;
+  const int n0 = (blockIdx.x * nqb + nq) * 4;
+  const int lblk = blockIdx.y * nsl * LRTC_LT;
+  for (int i = threadIdx.x; i < nsl * LRTC_LT * RT; i += 256) {
+    const int li = i / RT, r = i - li * RT;
+    const int l = lblk + li;
+    bs[i] = (l < L && r < R) ? basis[(size_t)l * R + r] : 0.f;
+  }
+  __syncthreads();
+  const int l0 = lblk + sl * LRTC_LT;
+  if (n0 >= N || l0 >= L) return;
   const float scale = *scale_p;
   float co[4][RT];
 #pragma unroll
@@ -93,12 +106,13 @@ __global__ __launch_bounds__(256) void k_lrtc(const float* __restrict__ coeff, c
     for (int k = 0; k < 4; ++k) mu[k] = fmaf(cm, co[k][r], mu[k]);
   }
   const int l1 = min(l0 + LRTC_LT, L);
-  for (int l = l0; l < l1; ++l) {
-    const float* __restrict__ brow = basis + (size_t)l * R;
+  const float* __restrict__ brow = bs + sl * LRTC_LT * RT;
+#pragma unroll 2
+  for (int l = l0; l < l1; ++l, brow += RT) {
     float acc[4] = {-mu[0], -mu[1], -mu[2], -mu[3]};
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-      const float bv = r < R ? brow[r] : 0.f;
+      const float bv = brow[r];
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[k] = fmaf(bv, co[k][r], acc[k]);
     }
@@ -117,11 +131,11 @@ __global__ __launch_bounds__(256) void k_lrtc(const float* __restrict__ coeff, c
 
 template <int RT>
 static void launch_lrtc(dim3 grid, hipStream_t st, bool vec, bool addx, const float* coeff, const float* basis,
-                        const float* scale, const float* x, float* out, int L, int N, int R) {
-  if (vec && addx) hipLaunchKernelGGL((k_lrtc<RT, true, true>), grid, dim3(256), 0, st, coeff, basis, scale, x, out, L, N, R);
-  else if (vec) hipLaunchKernelGGL((k_lrtc<RT, true, false>), grid, dim3(256), 0, st, coeff, basis, scale, x, out, L, N, R);
-  else if (addx) hipLaunchKernelGGL((k_lrtc<RT, false, true>), grid, dim3(256), 0, st, coeff, basis, scale, x, out, L, N, R);
-  else hipLaunchKernelGGL((k_lrtc<RT, false, false>), grid, dim3(256), 0, st, coeff, basis, scale, x, out, L, N, R);
+                        const float* scale, const float* x, float* out, int L, int N, int R, int nqb) {
+  if (vec && addx) hipLaunchKernelGGL((k_lrtc<RT, true, true>), grid, dim3(256), 0, st, coeff, basis, scale, x, out, L, N, R, nqb);
+  else if (vec) hipLaunchKernelGGL((k_lrtc<RT, true, false>), grid, dim3(256), 0, st, coeff, basis, scale, x, out, L, N, R, nqb);
+  else if (addx) hipLaunchKernelGGL((k_lrtc<RT, false, true>), grid, dim3(256), 0, st, coeff, basis, scale, x, out, L, N, R, nqb);
+  else hipLaunchKernelGGL((k_lrtc<RT, false, false>), grid, dim3(256), 0, st, coeff, basis, scale, x, out, L, N, R, nqb);
 }
 
 // basis_dev is what ftn_lrtc_basis wrote: [L][R] basis followed by R column means.
@@ -135,11 +149,14 @@ extern "C" int ftn_lrtc_forward(const float* coeff_dev, const float* basis_dev, 
   hipStream_t st = (hipStream_t)stream;
   const bool addx = x_dev_or_null != nullptr;
   const bool vec = (N % 4 == 0) && (((uintptr_t)out_dev & 15) == 0) && (!addx || ((uintptr_t)x_dev_or_null & 15) == 0);
-  dim3 grid(ftn_cdiv(N, 1024), ftn_cdiv(L, LRTC_LT), B);
-  if (R <= 4) launch_lrtc<4>(grid, st, vec, addx, coeff_dev, basis_dev, scale_dev, x_dev_or_null, out_dev, L, N, R);
-  else if (R <= 8) launch_lrtc<8>(grid, st, vec, addx, coeff_dev, basis_dev, scale_dev, x_dev_or_null, out_dev, L, N, R);
-  else if (R <= 16) launch_lrtc<16>(grid, st, vec, addx, coeff_dev, basis_dev, scale_dev, x_dev_or_null, out_dev, L, N, R);
-  else launch_lrtc<32>(grid, st, vec, addx, coeff_dev, basis_dev, scale_dev, x_dev_or_null, out_dev, L, N, R);
+  int nqb = ((ftn_cdiv(N, 4) + 63) / 64) * 64;
+  if (nqb > 256) nqb = 256;
+  if (nqb == 192) nqb = 256;   // 256 / nqb must be integral
+  dim3 grid(ftn_cdiv(N, 4 * nqb), ftn_cdiv(L, LRTC_LT * (256 / nqb)), B);
+  if (R <= 4) launch_lrtc<4>(grid, st, vec, addx, coeff_dev, basis_dev, scale_dev, x_dev_or_null, out_dev, L, N, R, nqb);
+  else if (R <= 8) launch_lrtc<8>(grid, st, vec, addx, coeff_dev, basis_dev, scale_dev, x_dev_or_null, out_dev, L, N, R, nqb);
+  else if (R <= 16) launch_lrtc<16>(grid, st, vec, addx, coeff_dev, basis_dev, scale_dev, x_dev_or_null, out_dev, L, N, R, nqb);
+  else launch_lrtc<32>(grid, st, vec, addx, coeff_dev, basis_dev, scale_dev, x_dev_or_null, out_dev, L, N, R, nqb);
   FTN_CHECK_LAUNCH();
   return 0;
 }

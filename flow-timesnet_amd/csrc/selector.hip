@@ -54,6 +54,52 @@ extern "C" int ftn_dft_table_init(void* table_dev, int L, void* stream) {
 // channels (B = x[b][t][c], C fastest -> 128 contiguous bytes per half-wave).
 // The amplitude tile goes to LDS and the lower median over channels is taken by
 // rank counting (exact ties broken by channel index, i.e. a stable sort).
+// Ascending bitonic sort of 64*V values held as V registers per lane (element index =
+// 64*i + lane), then the lower median sorted[(C-1)/2]; padding is +inf.  21 compare-exchange
+// steps for 64 channels instead of a 64x64 rank count.
+template <int V>
+__device__ __forceinline__ float wave_lower_median(const float* __restrict__ row, int C, int lane) {
+  float v[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = c < C ? row[c] : INFINITY;
+  }
+#pragma unroll
+  for (int k = 2; k <= 64 * V; k <<= 1) {
+#pragma unroll
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      if (jj >= 64) {
+        const int di = jj >> 6;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          if ((i & di) == 0) {
+            const bool up = ((i * 64) & k) == 0;   // lane bits never reach k >= 128
+            const float lo = fminf(v[i], v[i | di]), hi = fmaxf(v[i], v[i | di]);
+            v[i] = up ? lo : hi;
+            v[i | di] = up ? hi : lo;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const int e = i * 64 + lane;
+          const float other = __shfl_xor(v[i], jj);
+          const bool up = (e & k) == 0;
+          const bool lower = (lane & jj) == 0;
+          v[i] = (lower == up) ? fminf(v[i], other) : fmaxf(v[i], other);
+        }
+      }
+    }
+  }
+  const int t = (C - 1) >> 1;
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i)
+    if ((t >> 6) == i) m = __shfl(v[i], t & 63);
+  return m;
+}
+
 __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, int L, int C,
                                                   const float* __restrict__ tab, int F, int FPAD,
                                                   float* __restrict__ med) {
@@ -70,23 +116,38 @@ __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, i
     const int c = ct * 32 + i;
     const bool cok = c < C;
     f16v re = {0}, im = {0};
-    // 8 k-steps (16 time samples) per iteration: 24 independent loads are in flight
-    // before the 16 MFMAs that consume them
-    for (int t = 0; t < L; t += 16) {
+    // 8 k-steps (16 time samples) per iteration: 24 independent loads are in flight before
+    // the 16 MFMAs that consume them.  Addresses advance by constant strides (no per-load
+    // 64-bit multiply, no bounds test) in the main loop; the ragged tail is guarded.
+    const float* pc = ctab + (size_t)h * FPAD;
+    const float* ps = stab + (size_t)h * FPAD;
+    const float* px = xb + (size_t)h * C + (cok ? c : 0);
+    const int sT = 2 * FPAD, sX = 2 * C;
+    int t = 0;
+    for (; t + 16 <= L; t += 16) {
       float ac[8], as[8], bv[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int tt = t + 2 * k + h;
-        const bool tok = tt < L;
-        ac[k] = tok ? ctab[(size_t)tt * FPAD] : 0.f;
-        as[k] = tok ? stab[(size_t)tt * FPAD] : 0.f;
-        bv[k] = (tok && cok) ? xb[(size_t)tt * C + c] : 0.f;
+        ac[k] = pc[k * sT];
+        as[k] = ps[k * sT];
+        bv[k] = px[k * sX];
       }
+      pc += 8 * sT; ps += 8 * sT; px += 8 * sX;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[k], bv[k], re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k], bv[k], im, 0, 0, 0);
+        const float xv = cok ? bv[k] : 0.f;
+        re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[k], xv, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k], xv, im, 0, 0, 0);
       }
+    }
+    for (; t < L; t += 2) {
+      const int tt = t + h;
+      const bool tok = tt < L;
+      const float ac = tok ? ctab[(size_t)tt * FPAD] : 0.f;
+      const float as = tok ? stab[(size_t)tt * FPAD] : 0.f;
+      const float bv = (tok && cok) ? xb[(size_t)tt * C + c] : 0.f;
+      re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bv, re, 0, 0, 0);
+      im = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bv, im, 0, 0, 0);
     }
     if (cok) {
 #pragma unroll
@@ -101,14 +162,23 @@ __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, i
   for (int fl = wave; fl < 32; fl += nw) {
     if (f0 + fl >= F) break;
     const float* __restrict__ row = amp + fl * CS;
-    for (int c = lane; c < C; c += 64) {
-      const float v = row[c];
-      int cnt = 0;
-      for (int c2 = 0; c2 < C; ++c2) {
-        const float v2 = row[c2];
-        cnt += (v2 < v || (v2 == v && c2 < c)) ? 1 : 0;
+    if (C <= 256) {
+      float m;
+      if (C <= 64) m = wave_lower_median<1>(row, C, lane);
+      else if (C <= 128) m = wave_lower_median<2>(row, C, lane);
+      else m = wave_lower_median<4>(row, C, lane);
+      if (lane == 0) med[(size_t)b * F + f0 + fl] = m;
+    } else {
+      // generic: stable rank count
+      for (int c = lane; c < C; c += 64) {
+        const float v = row[c];
+        int cnt = 0;
+        for (int c2 = 0; c2 < C; ++c2) {
+          const float v2 = row[c2];
+          cnt += (v2 < v || (v2 == v && c2 < c)) ? 1 : 0;
+        }
+        if (cnt == target) med[(size_t)b * F + f0 + fl] = v;
       }
-      if (cnt == target) med[(size_t)b * F + f0 + fl] = v;
     }
   }
 }

@@ -511,10 +511,19 @@ class LowRankTemporalContext(nn.Module):
             from .. import runtime
 
             self._last_backend = "hip"
-            cf = coeff.detach().float().contiguous()
-            xa = None if add_to is None else add_to.detach().float().contiguous()
-            out = runtime.lrtc_forward(cf, int(length), self.scale.detach().float().to(coeff.device), xa)
-            return out.to(coeff.dtype)
+            cf = coeff.detach()
+            if cf.dtype != torch.float32 or not cf.is_contiguous():
+                cf = cf.float().contiguous()
+            xa = None
+            if add_to is not None:
+                xa = add_to.detach()
+                if xa.dtype != torch.float32 or not xa.is_contiguous():
+                    xa = xa.float().contiguous()
+            sc = self.scale.detach()
+            if sc.dtype != torch.float32 or sc.device != cf.device:
+                sc = sc.to(device=cf.device, dtype=torch.float32)
+            out = runtime.lrtc_forward(cf, int(length), sc, xa)
+            return out if out.dtype == coeff.dtype else out.to(coeff.dtype)
         self._last_backend = "torch"
         ctx = torch.einsum("lr,bnr->bln", self._basis(length, coeff), coeff)
         ctx = (ctx - ctx.mean(dim=1, keepdim=True)) * self.scale.to(device=coeff.device, dtype=coeff.dtype)
