@@ -124,20 +124,33 @@ __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, i
     const float* px = xb + (size_t)h * C + (cok ? c : 0);
     const int sT = 2 * FPAD, sX = 2 * C;
     int t = 0;
-    for (; t + 16 <= L; t += 16) {
-      float ac[8], as[8], bv[8];
+    // two-deep software pipeline: the loads of block i+1 are issued before the MFMAs of
+    // block i (sched_barrier keeps hipcc from sinking them back next to their uses)
+    float ac[8], as[8], bv[8];
+    if (L >= 16) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        ac[k] = pc[k * sT];
-        as[k] = ps[k * sT];
-        bv[k] = px[k * sX];
-      }
+      for (int k = 0; k < 8; ++k) { ac[k] = pc[k * sT]; as[k] = ps[k * sT]; bv[k] = px[k * sX]; }
       pc += 8 * sT; ps += 8 * sT; px += 8 * sX;
+    }
+    for (; t + 16 <= L; t += 16) {
+      float an[8], sn[8], bn[8];
+      const bool more = t + 32 <= L;   // wave-uniform
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { an[k] = pc[k * sT]; sn[k] = ps[k * sT]; bn[k] = px[k * sX]; }
+        pc += 8 * sT; ps += 8 * sT; px += 8 * sX;
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float xv = cok ? bv[k] : 0.f;
         re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[k], xv, re, 0, 0, 0);
         im = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k], xv, im, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ac[k] = an[k]; as[k] = sn[k]; bv[k] = bn[k]; }
       }
     }
     for (; t < L; t += 2) {
