@@ -96,6 +96,15 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = Path(os.environ.get("FLOWTIMES_LIB", LIB_PATH))
+    if not path.exists() and "FLOWTIMES_LIB" not in os.environ:
+        # in-tree build on first use (hipcc cross-compiles gfx950 without a GPU); a failed
+        # build is an error, never a fallback
+        import shutil
+        import subprocess
+
+        if shutil.which("make") and (shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists()):
+            subprocess.run(["make", "-C", str(_HERE / "csrc"), "-j4"], check=False,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if not path.exists():
         raise FlowTimesLibraryError(
             f"{path} not found: build it with `make -C {_HERE / 'csrc'}` "
