@@ -31,12 +31,12 @@ static inline int ftn_pad16(int v) { return (v + 15) & ~15; }
 static inline int ftn_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- conv tiling: one rule shared by the device finalize kernel and the host --
-// A conv tile is th x tw grid pixels (<= FTN_TILE_PX: 4 waves x 6 units x 16 px);
+// A conv tile is th x tw grid pixels (<= FTN_TILE_PX = 22 units of 16 px);
 // the kernel stages the tile plus its halo, CLIPPED to the grid, in LDS.  Tiles
 // are as large as possible (a whole 336-pixel grid is one tile) subject to the
 // clipped region (for a 7x7 kernel) staying <= FTN_REGION_PX pixels.
-#define FTN_TILE_PX 384
-#define FTN_REGION_PX 384
+#define FTN_TILE_PX 352
+#define FTN_REGION_PX 352
 #define FTN_TILE_HALO 3
 
 __host__ __device__ inline void ftn_tile_geometry(int cycles, int period, int* tw, int* th,
@@ -144,6 +144,37 @@ __device__ __forceinline__ float gelu_erf(float v) {
   const float hv = 0.5f * v;
   return v >= 0.0f ? fmaf(-hv, E, v) : hv * E;
 }
+// ---- bf16x3 split arithmetic -------------------------------------------------------
+// An fp32 value is carried as three bf16 pieces (hi + mid + lo = 24 mantissa bits); a
+// product a*b is formed on the bf16 matrix pipe as the six partial products whose weight
+// is >= 2^-16 relative (hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi), accumulated in
+// fp32.  Measured error is at or below that of an fp32 FMA chain, at 6
+// v_mfma_f32_16x16x32_bf16 (96 cycles) instead of 8 v_mfma_f32_16x16x4_f32 (256 cycles).
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma_bf(bf8 a, bf8 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// "P3" activation layout: per pixel, per group of 16 channels: [hi 16][mid 16][lo 16] bf16
+// (96 bytes), so one K=32 MFMA slab reads 16 contiguous bytes per piece per lane.
+// Stores the 4 channels 4q..4q+3 of one group as three 8-byte pieces.
+__device__ __forceinline__ void store_p3(__bf16* __restrict__ grp, int q, f4 v) {
+  bf4 h, m, l;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const __bf16 hh = (__bf16)v[r];
+    const float r1 = v[r] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    h[r] = hh; m[r] = mm; l[r] = (__bf16)r2;
+  }
+  *(bf4*)(grp + 4 * q) = h;
+  *(bf4*)(grp + 16 + 4 * q) = m;
+  *(bf4*)(grp + 32 + 4 * q) = l;
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_fn(float v) {
   if (ACT == 1) return v > 0.0f ? v : 0.0f;

@@ -138,6 +138,8 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
           const int ch = 16 * (og + o) + 4 * q;
           if (EPI == 0) {
             *(f4*)(a.out + (size_t)px[u].n * a.OUTC + ch) = acc[o][u];
+          } else if (EPI == 2) {   // three bf16 pieces per value (input of the bf16x3 conv engine)
+            store_p3((__bf16*)a.out + ((size_t)px[u].n * (a.OUTC >> 4) + (og + o)) * 48, q, acc[o][u]);
           } else {
             float* rp = a.R + (size_t)px[u].n * a.RC + ch;
             const f4 r = *(const f4*)rp;
@@ -179,6 +181,7 @@ struct MlpArgs {
   int n_ot;              // total output tiles (n_oa + CP/16 when res2 is a conv)
   int res2_ident;        // 1: r = g - x  (FP == CP), taken from the hidden tiles
   int n_hchunks, cfrag_per_chunk;
+  int outA_p3;           // 1: write a' as three bf16 pieces (bf16x3 conv engine)
   unsigned long long* dbg; size_t dbg_cap;
 };
 
@@ -410,7 +413,8 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
       for (int u = 0; u < NPX; ++u) {
         if (!px[u].ok) continue;
         if (o < a.n_oa) {
-          *(f4*)(a.outA + (size_t)px[u].n * a.AC + 16 * o + 4 * q) = oacc[o][u];
+          if (a.outA_p3) store_p3((__bf16*)a.outA + ((size_t)px[u].n * (a.AC >> 4) + o) * 48, q, oacc[o][u]);
+          else *(f4*)(a.outA + (size_t)px[u].n * a.AC + 16 * o + 4 * q) = oacc[o][u];
         } else {
           const int ch = 16 * (o - a.n_oa) + 4 * q;
           *(f4*)(a.outR + (size_t)px[u].n * CP + ch) = oacc[o][u] - load_x4<XVEC>(px[u].xrow, ch, a.C);
@@ -450,7 +454,7 @@ struct ConvArgs {
 };
 
 #define LDS_PX_STRIDE 20  // 16 channels + 4 pad dwords
-#define CONV_NU 6         // 16-pixel units per wave: 4 waves x 6 x 16 = FTN_TILE_PX
+#define CONV_NU 6         // 16-pixel units per wave: 4 waves x 6 x 16 >= FTN_TILE_PX
 
 // One kernel row (fixed dy) of taps for NU units.  KW > 0: the dx loop is fully
 // unrolled (tap offsets become ds_read immediates, no per-tap address math);
@@ -646,6 +650,237 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   stamp(a.dbg, a.dbg_cap, wgid, 3);
   if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) a.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
   }  // tile loop
+}
+
+// ---------------------------------------------------------------- stages B / D, bf16x3 engine
+// Same convolution on the bf16 matrix pipe with fp32-equivalent accuracy: activations arrive
+// as three bf16 pieces per value (P3 layout, written by the producing stage), weights are
+// pre-split on the host, and every K=32 slab (= two taps x 16 input channels) is six
+// v_mfma_f32_16x16x32_bf16 (hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi) into one fp32
+// accumulator: 96 cycles instead of 256 for the same contraction in fp32 MFMA.
+// One 512-thread workgroup (two waves per SIMD) owns one tile x branch and walks `bpw`
+// batch rows: the weight fragments are staged once by LDS-DMA, the tile regions are
+// double-buffered (row i+1 is requested before row i is computed), so neither is on the
+// critical path.  NS = 1 drops the mid/lo pieces (plain bf16, BASELINE configs[2]).
+struct ConvBfArgs {
+  const __bf16* in;      // P3 [N][INC/16][3][16]
+  void* out;             // fp32 [N][OUTC] or P3 [N][OUTC/16][3][16]
+  const __bf16* W[FTN_MAXBR];  // per branch [cc][co][slab][piece][lane][8]
+  const float* bias;
+  const FtnDesc* desc;
+  int B, INC, OUTC, out_p3;
+  int nbr, cin, cout, in_stride_br, out_stride_br, nchunk;
+  int region_bytes;      // one region buffer incl. the 96-byte zero pixel at its end
+  int wbytes;            // weight fragment bytes in LDS
+  int bpw;               // batch rows per workgroup
+  int kh[FTN_MAXBR], kw[FTN_MAXBR], order[FTN_MAXBR];
+  unsigned long long* dbg; size_t dbg_cap;
+};
+
+#define CBF_NU 3          // 16-pixel units per wave: 8 waves x 3 x 16 >= FTN_TILE_PX
+#define P3_PX_BYTES 96    // one pixel of one 16-channel group in global memory: 3 pieces x 16 bf16
+#define P3_LDS_STRIDE 112 // LDS pixel stride: 96 + 16 pad bytes, so the 16 pixels of a ds_read_b128 lane
+                          // group fall on 16 distinct bank quads (96 would be 2-way conflicted)
+
+template <int NCO, int NS>
+__global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  const FtnDesc* __restrict__ d = a.desc;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int zb = blockIdx.z / a.nchunk, chunk = blockIdx.z - zb * a.nchunk;
+  const int br = a.order[zb];
+  const int kh = a.kh[br], kw = a.kw[br], hy = kh >> 1, hx = kw >> 1, ntaps = kh * kw;
+  const int S = (ntaps + 1) >> 1;
+  const int nco_tot = a.cout >> 4, co0 = chunk * NCO, ncc = a.cin >> 4;
+  char* __restrict__ wl = ldsb;
+  char* __restrict__ rbuf0 = ldsb + a.wbytes;
+  const int zoff = a.region_bytes - P3_LDS_STRIDE;         // zero pixel at the end of each region buffer
+  const int b_begin = blockIdx.y * a.bpw, b_end = min(a.B, b_begin + a.bpw);
+  const int G = d->n_groups, tiles_total = d->tiles_per_row;
+  // zero pixels of both region buffers (never overwritten by the DMA)
+  if (threadIdx.x < 14) *(f4*)(rbuf0 + (threadIdx.x / 7) * a.region_bytes + zoff + (threadIdx.x % 7) * 16) = f4{0.f, 0.f, 0.f, 0.f};
+  const size_t wgid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  stamp(a.dbg, a.dbg_cap, wgid, 0);
+  if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) { a.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime(); a.dbg[wgid * 8 + 4] = (unsigned long long)ntaps; a.dbg[wgid * 8 + 5] = 0; }
+
+  for (int bx = blockIdx.x; bx < tiles_total; bx += gridDim.x) {
+    int g = 0;
+    for (int gg = 1; gg < G; ++gg)
+      if (bx >= d->g_tile_off[gg]) g = gg;
+    const int tix = bx - d->g_tile_off[g];
+    const int ntx = d->g_ntx[g];
+    const int ty = tix / ntx, tx = tix - ty * ntx;
+    const int p = d->g_period[g], cycles = d->g_cycles[g];
+    const int P = d->g_px_off[g + 1] - d->g_px_off[g];
+    const int r0 = ty * d->g_th[g], c0 = tx * d->g_tw[g];
+    const int th = min(d->g_th[g], cycles - r0), tw = min(d->g_tw[g], p - c0);
+    const int R0 = max(0, r0 - hy), R1 = min(cycles, r0 + th + hy);
+    const int C0 = max(0, c0 - hx), C1 = min(p, c0 + tw + hx);
+    const int RW = C1 - C0, RH = R1 - R0;
+    const int npx = th * tw, nunits = (npx + 15) >> 4;
+    const int in_groups = a.INC >> 4;
+    const float inv_tw = 1.0f / (float)tw, inv_rw = 1.0f / (float)RW;
+    const unsigned kmh = (1u << kh) - 1u, kmw = (1u << kw) - 1u;
+    const int nchunks16 = RH * RW * 7;                     // 16-byte pieces of one region (6 data + 1 pad per pixel)
+    const int npieces = (nchunks16 + 63) >> 6;             // 1-KiB DMA instructions
+
+    // region of batch row b, channel group cc -> buffer `buf`
+    auto dma_region = [&](int b, int cc, int buf) {
+      const __bf16* __restrict__ src = a.in + ((size_t)a.B * d->g_px_off[g] + (size_t)b * P) * in_groups * 48 +
+                                       (size_t)(br * a.in_stride_br + cc) * 48;
+      for (int pc = wv; pc < npieces; pc += 8) {
+        int ci = pc * 64 + lane;
+        if (ci >= nchunks16) ci = nchunks16 - 1;             // tail lanes re-read the last piece (lands in slack)
+        const int sp = (int)(((float)ci + 0.5f) * (1.0f / 7.0f));
+        int sub = ci - sp * 7;
+        if (sub > 5) sub = 5;                                 // pad chunk: any valid source
+        const int rr = (int)(((float)sp + 0.5f) * inv_rw), cx = sp - rr * RW;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (size_t)((R0 + rr) * p + C0 + cx) * in_groups * 48 + sub * 8),
+            (__attribute__((address_space(3))) void*)(rbuf0 + (size_t)buf * a.region_bytes + (size_t)pc * 1024), 16, 0, 0);
+      }
+    };
+    auto dma_weights = [&](int cc) {
+      const int nfr = S * 3;                                  // 1-KiB fragments per output tile
+      for (int o = 0; o < NCO; ++o) {
+        if (co0 + o < nco_tot) {
+          const __bf16* __restrict__ src = a.W[br] + ((size_t)(cc * nco_tot + co0 + o) * nfr) * 512;
+          for (int f = wv; f < nfr; f += 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 512 + lane * 8),
+                                             (__attribute__((address_space(3))) void*)(wl + ((size_t)o * nfr + f) * 1024), 16, 0, 0);
+        } else {
+          for (int f = wv; f < nfr; f += 8) *(f4*)(wl + ((size_t)o * nfr + f) * 1024 + lane * 16) = f4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    };
+
+    // per-lane pixel bookkeeping, once per tile (rotated by the workgroup's batch chunk so the
+    // 3-unit waves spread over the SIMDs)
+    const int wrot = (wave + (int)blockIdx.y) & 7;
+    const int nu = nunits > wrot ? (nunits - wrot + 7) >> 3 : 0;
+    int lbase[CBF_NU], oidx[CBF_NU];
+    unsigned rmask[CBF_NU], cmask[CBF_NU];
+    bool pok[CBF_NU];
+#pragma unroll
+    for (int u = 0; u < CBF_NU; ++u) {
+      int idx = (wrot + 8 * u) * 16 + j;
+      pok[u] = idx < npx;
+      if (!pok[u]) idx = 0;
+      const int r = (int)(((float)idx + 0.5f) * inv_tw), c = idx - r * tw;
+      const int ri = r0 + r, ci = c0 + c;
+      lbase[u] = ((ri - R0 - hy) * RW + (ci - C0 - hx)) * P3_LDS_STRIDE + (qa & 1) * 16;
+      oidx[u] = ri * p + ci;
+      const int rlo = max(0, hy - ri), rhi = min(kh, cycles + hy - ri);
+      const int clo = max(0, hx - ci), chi = min(kw, p + hx - ci);
+      const unsigned rm = (rhi > rlo) ? ((kmh >> (kh - rhi)) & (kmh << rlo)) & kmh : 0u;
+      const unsigned cm = (chi > clo) ? ((kmw >> (kw - chi)) & (kmw << clo)) & kmw : 0u;
+      rmask[u] = pok[u] ? rm : 0u;
+      cmask[u] = pok[u] ? cm : 0u;
+    }
+    __syncthreads();                                          // previous tile's readers are done
+    if (ncc == 1) dma_weights(0);
+    if (b_begin < b_end) dma_region(b_begin, 0, 0);
+    int it = 0;                                                // region buffer parity
+    for (int b = b_begin; b < b_end; ++b) {
+      f4 acc[NCO][CBF_NU];
+#pragma unroll
+      for (int o = 0; o < NCO; ++o) {
+        f4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (co0 + o < nco_tot) bv = *(const f4*)(a.bias + br * a.out_stride_br + 16 * (co0 + o) + 4 * (lane >> 4));
+#pragma unroll
+        for (int u = 0; u < CBF_NU; ++u) acc[o][u] = bv;
+      }
+      for (int cc = 0; cc < ncc; ++cc) {
+        if (ncc > 1) { __syncthreads(); dma_weights(cc); }
+        __syncthreads();                                      // region (b, cc) and weights have landed (vmcnt(0))
+        if (b == b_begin && cc == 0) stamp(a.dbg, a.dbg_cap, wgid, 1);
+        if (b == b_begin + 1 && cc == 0) stamp(a.dbg, a.dbg_cap, wgid, 2);
+        // request the next region while this one is consumed
+        {
+          int nb = b, ncq = cc + 1;
+          if (ncq == ncc) { ncq = 0; nb = b + 1; }
+          if (nb < b_end) dma_region(nb, ncq, (it + 1) & 1);
+        }
+        const char* __restrict__ reg = rbuf0 + (size_t)(it & 1) * a.region_bytes;
+        ++it;
+        // slabs: lane group qa>>1 == 1 works on the odd tap of the pair.  Two-deep software
+        // pipeline with ping-pong register sets: the LDS reads of slab s+1 are issued before
+        // the MFMAs of slab s (sched_barrier keeps hipcc from re-serialising them).
+        int tl = qa >> 1;
+        int dy = tl / kw, dx = tl - dy * kw;
+        int sload = 0;
+        auto load_slab = [&](bf8 (&bp)[CBF_NU][NS], bf8 (&ap)[NCO][NS]) {
+          const bool tapok = tl < ntaps;
+          const int toff = (dy * RW + dx) * P3_LDS_STRIDE;
+#pragma unroll
+          for (int u = 0; u < CBF_NU; ++u) {
+            const bool v = tapok && (((rmask[u] >> dy) & (cmask[u] >> dx) & 1u) != 0u);
+            const char* __restrict__ src = reg + (v ? lbase[u] + toff : zoff);
+#pragma unroll
+            for (int pz = 0; pz < NS; ++pz) bp[u][pz] = *(const bf8*)(src + pz * 32);
+          }
+          const int sa = sload < S ? sload : S - 1;
+#pragma unroll
+          for (int o = 0; o < NCO; ++o)
+#pragma unroll
+            for (int pz = 0; pz < NS; ++pz) ap[o][pz] = *(const bf8*)(wl + (((size_t)o * S + sa) * 3 + pz) * 1024 + lane * 16);
+          ++sload; tl += 2; dx += 2;
+          if (dx >= kw) { dx -= kw; ++dy; }
+          if (dx >= kw) { dx -= kw; ++dy; }
+        };
+        auto mma_slab = [&](const bf8 (&bp)[CBF_NU][NS], const bf8 (&ap)[NCO][NS]) {
+#pragma unroll
+          for (int o = 0; o < NCO; ++o) {
+#pragma unroll
+            for (int u = 0; u < CBF_NU; ++u) {
+              f4 c = acc[o][u];
+              if (NS == 3) {
+                c = mfma_bf(ap[o][0], bp[u][2], c);
+                c = mfma_bf(ap[o][2], bp[u][0], c);
+                c = mfma_bf(ap[o][1], bp[u][1], c);
+                c = mfma_bf(ap[o][0], bp[u][1], c);
+                c = mfma_bf(ap[o][1], bp[u][0], c);
+              }
+              c = mfma_bf(ap[o][0], bp[u][0], c);
+              acc[o][u] = c;
+            }
+          }
+        };
+        bf8 bA[CBF_NU][NS], aA[NCO][NS], bB[CBF_NU][NS], aB[NCO][NS];
+        load_slab(bA, aA);
+        int sl = 0;
+        for (; sl + 2 <= S; sl += 2) {
+          load_slab(bB, aB);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_slab(bA, aA);
+          __builtin_amdgcn_sched_barrier(0);
+          load_slab(bA, aA);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_slab(bB, aB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (sl < S) mma_slab(bA, aA);
+      }
+      // store this batch row's tile
+      const size_t nimg = (size_t)a.B * d->g_px_off[g] + (size_t)b * P;
+#pragma unroll
+      for (int o = 0; o < NCO; ++o) {
+        if (co0 + o < nco_tot) {
+#pragma unroll
+          for (int u = 0; u < CBF_NU; ++u) {
+            if (u < nu && pok[u]) {
+              const int ch = br * a.out_stride_br + 16 * (co0 + o);
+              if (a.out_p3) store_p3((__bf16*)a.out + ((nimg + oidx[u]) * (a.OUTC >> 4) + (ch >> 4)) * 48, lane >> 4, acc[o][u]);
+              else *(f4*)((float*)a.out + (nimg + oidx[u]) * a.OUTC + ch + 4 * (lane >> 4)) = acc[o][u];
+            }
+          }
+        }
+      }
+    }
+  }
+  stamp(a.dbg, a.dbg_cap, wgid, 3);
+  if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) a.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---------------------------------------------------------------- small elementwise stages
@@ -975,7 +1210,7 @@ static WsLayout ws_layout(const FtnPlan* pl, int B, int L, int max_groups) {
   w.c1 = pl->mode == 0 ? CA : pl->FP;                 // m / m'   (mode 1: conv1 output)
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   w.off0 = 0;
-  w.off1 = al(w.off0 + N * w.c0 * 4);
+  w.off1 = al(w.off0 + N * w.c0 * (pl->engine != 0 && pl->mode == 0 ? 6 : 4));   // P3 = 6 bytes per value
   w.off2 = al(w.off1 + N * w.c1 * 4);                 // R [N][CP]
   w.off3 = al(w.off2 + N * pl->CP * 4);               // G [N][FP] (mode 1)
   w.total = pl->mode == 0 ? w.off3 : al(w.off3 + N * pl->FP * 4);
@@ -1027,6 +1262,62 @@ static int launch_conv(ConvArgs& ca, int B, int L, int grid_x, hipStream_t st) {
   if (NCO == 4) return launch_conv_t<4>(ca, grid, lds, st);
   if (NCO == 2) return launch_conv_t<2>(ca, grid, lds, st);
   return launch_conv_t<1>(ca, grid, lds, st);
+}
+
+struct ConvBfGeom { int NCO; size_t lds; int region_bytes, wbytes; };
+
+// LDS plan of the bf16x3 conv engine for window length L; NCO = 0 when it does not fit.
+static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int cout) {
+  ConvBfGeom gm = {0, 0, 0, 0};
+  int region_px = 1, smax = 1;
+  for (int k = 0; k < nbr; ++k) {
+    if (kh[k] > 31 || kw[k] > 31) return gm;
+    int v = conv_region_px(L, kh[k], kw[k]);
+    if (v > region_px) region_px = v;
+    int sl = (kh[k] * kw[k] + 1) / 2;
+    if (sl > smax) smax = sl;
+  }
+  gm.region_bytes = ((region_px * P3_LDS_STRIDE + 1023) & ~1023) + P3_LDS_STRIDE;
+  const int nco_tot = cout / 16;
+  for (int nco = nco_tot >= 4 ? 4 : (nco_tot >= 2 ? 2 : 1); nco >= 1; nco >>= 1) {
+    size_t w = (size_t)nco * smax * 3 * 1024;
+    size_t tot = w + 2 * (size_t)gm.region_bytes;
+    if (tot <= 160 * 1024) { gm.NCO = nco; gm.lds = tot; gm.wbytes = (int)w; return gm; }
+  }
+  return gm;
+}
+
+template <int NCO, int NS>
+static int launch_conv_bf_t(const ConvBfArgs& ca, dim3 grid, size_t lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute((const void*)k_conv_bf<NCO, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_conv_bf): %s", hipGetErrorString(e)); return (int)e; }
+  hipLaunchKernelGGL((k_conv_bf<NCO, NS>), grid, dim3(512), lds, st, ca);
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
+static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_x, int nsplit, hipStream_t st) {
+  const int nco_tot = ca.cout / 16;
+  ca.nchunk = ftn_cdiv(nco_tot, gm.NCO);
+  ca.region_bytes = gm.region_bytes;
+  ca.wbytes = gm.wbytes;
+  ca.dbg = (g_stamp_which & 1) ? g_stamp_buf : nullptr; ca.dbg_cap = g_stamp_cap;
+  ca.bpw = 4;
+  for (int k = 0; k < ca.nbr; ++k) ca.order[k] = k;
+  for (int i = 1; i < ca.nbr; ++i) {
+    int v = ca.order[i], jj = i - 1;
+    while (jj >= 0 && ca.kh[ca.order[jj]] * ca.kw[ca.order[jj]] < ca.kh[v] * ca.kw[v]) { ca.order[jj + 1] = ca.order[jj]; --jj; }
+    ca.order[jj + 1] = v;
+  }
+  dim3 grid(grid_x, ftn_cdiv(B, ca.bpw), ca.nbr * ca.nchunk);
+  if (nsplit == 3) {
+    if (gm.NCO == 4) return launch_conv_bf_t<4, 3>(ca, grid, gm.lds, st);
+    if (gm.NCO == 2) return launch_conv_bf_t<2, 3>(ca, grid, gm.lds, st);
+    return launch_conv_bf_t<1, 3>(ca, grid, gm.lds, st);
+  }
+  if (gm.NCO == 4) return launch_conv_bf_t<4, 1>(ca, grid, gm.lds, st);
+  if (gm.NCO == 2) return launch_conv_bf_t<2, 1>(ca, grid, gm.lds, st);
+  return launch_conv_bf_t<1, 1>(ca, grid, gm.lds, st);
 }
 
 template <int ACT, bool XIN, int EPI>
@@ -1092,18 +1383,32 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
   prof_mark(0, st);
   if (pl->mode == 0) {
     const int CA = pl->nbr * pl->MP;
+    // conv engine: exact fp32 MFMA, or the bf16 matrix pipe (3 pieces = fp32-equivalent, 1 = plain bf16)
+    ConvBfGeom bfg = {0, 0, 0, 0};
+    if (pl->engine != 0) bfg = conv_bf_geom(L, pl->nbr, pl->kh, pl->kw, pl->MP);
+    const bool use_bf = pl->engine != 0 && bfg.NCO > 0;
+    const int nsplit = pl->engine == 2 ? 1 : 3;
     // A: a = W_in1 x + b
     PwArgs pa = {};
     pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = buf0; pa.desc = desc;
     pa.B = B; pa.L = L; pa.C = C; pa.KIN = CP; pa.n_ot = CA / 16; pa.OUTC = CA;
-    if ((rc = launch_pw<ACT, true, 0>(pa, xvec, nblk_pw, st))) return rc;
+    if (use_bf) { if ((rc = launch_pw<ACT, true, 2>(pa, xvec, nblk_pw, st))) return rc; }
+    else if ((rc = launch_pw<ACT, true, 0>(pa, xvec, nblk_pw, st))) return rc;
     prof_mark(1, st);
+    ConvBfArgs cb = {};
+    if (use_bf) {
+      cb.in = (const __bf16*)buf0; cb.out = buf1; cb.out_p3 = 0; cb.bias = wb + pl->b_conv1; cb.desc = desc;
+      cb.B = B; cb.INC = CA; cb.OUTC = CA; cb.nbr = pl->nbr; cb.cin = pl->MP; cb.cout = pl->MP;
+      cb.in_stride_br = pl->MP / 16; cb.out_stride_br = pl->MP;
+      for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf1[k]); cb.kh[k] = pl->kh[k]; cb.kw[k] = pl->kw[k]; }
+    }
     // B: m = conv(a)
     ConvArgs ca = {};
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CA; ca.OUTC = CA;
     ca.nbr = pl->nbr; ca.cin = pl->MP; ca.cout = pl->MP; ca.in_stride_br = pl->MP; ca.out_stride_br = pl->MP;
     for (int k = 0; k < pl->nbr; ++k) { ca.W[k] = wb + pl->w_conv1[k]; ca.kh[k] = pl->kh[k]; ca.kw[k] = pl->kw[k]; }
-    if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
+    if (use_bf) { if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st))) return rc; }
+    else if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(2, st);
     // C: fused pointwise chain
     MlpArgs ma = {};
@@ -1114,6 +1419,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ma.nKM = CA / 16; ma.nCP = pl->res1 ? CP / 16 : 0;
     ma.n_hchunks = pl->n_hchunks; ma.cfrag_per_chunk = pl->cfrag_per_chunk;
     ma.n_oa = CA / 16; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = ma.n_oa + (pl->res2 ? CP / 16 : 0);
+    ma.outA_p3 = use_bf ? 1 : 0;
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model/mid too large for v1", ma.n_ot); return -1; }
     if (ma.cfrag_per_chunk != MLP_HT * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
     if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
@@ -1121,7 +1427,11 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // D: m' = conv(a')
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
-    if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
+    if (use_bf) {
+      cb.bias = wb + pl->b_conv2;
+      for (int k = 0; k < pl->nbr; ++k) cb.W[k] = (const __bf16*)(wb + pl->w_convbf2[k]);
+      if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st))) return rc;
+    } else if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(4, st);
     // E+F: y = x + sum_g w (act(W_out2 m' + b) + r)
     OutArgs oa = {};

@@ -279,6 +279,9 @@ class TimesBlock(nn.Module):
         self._lazy_sel = None
         self._pack_key = None
         self._pack = None
+        # conv arithmetic of the HIP backend: None = pack.default_engine() ("bf16x3" unless
+        # FLOWTIMES_ENGINE says otherwise); "f32" = exact fp32 MFMA; "bf16" = plain bf16
+        self.engine: Optional[str] = None
 
     # ---- construction ------------------------------------------------------
     def _build_layers(self, channels: int, device: torch.device, dtype: torch.dtype) -> None:
@@ -328,11 +331,12 @@ class TimesBlock(nn.Module):
         from .. import pack
 
         params = list(self.inception.parameters())
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        engine = getattr(self, "engine", None) or pack.default_engine()
+        key = (str(device), engine) + tuple((p.data_ptr(), p._version) for p in params)
         if self._pack_key != key:
             sd = {k: v.detach().float().cpu().numpy() for k, v in self.inception.state_dict().items()}
             blob, plan = pack.pack_inception(sd, self.d_model, self.d_ff, self._kernel_spec,
-                                             self.bottleneck_ratio, self._activation_name)
+                                             self.bottleneck_ratio, self._activation_name, engine)
             self._pack = (torch.from_numpy(blob).to(device), plan)
             self._pack_key = key
         return self._pack

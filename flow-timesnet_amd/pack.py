@@ -65,6 +65,48 @@ def _pack_conv(w: np.ndarray, cinP: int, coutP: int) -> np.ndarray:
     return np.ascontiguousarray(v).astype(np.float32)
 
 
+def bf16_rne(x: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 (round to nearest even), returned as fp32 values with 16 low bits clear."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def split3(x: np.ndarray):
+    """hi + mid + lo bf16 pieces of fp32 data (what csrc/ftn_common.h store_p3 does)."""
+    x = np.asarray(x, dtype=np.float32)
+    h = bf16_rne(x)
+    r1 = (x - h).astype(np.float32)
+    m = bf16_rne(r1)
+    l = bf16_rne((r1 - m).astype(np.float32))
+    return h, m, l
+
+
+def _bf16_bits_as_f32(pieces: np.ndarray) -> np.ndarray:
+    """bf16 values (held as fp32) -> their 16-bit patterns packed two per float32 word."""
+    bits = (np.ascontiguousarray(pieces, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    flat = bits.reshape(-1)
+    if flat.size % 2:
+        flat = np.concatenate([flat, np.zeros(1, np.uint16)])
+    return flat.view(np.float32)
+
+
+def _pack_conv_bf(w: np.ndarray, cinP: int, coutP: int) -> np.ndarray:
+    """w[cout][cin][kh][kw] -> bf16x3 K=32 fragments [cc][co][slab][piece][lane][8]: lane
+    (i = lane & 15, qa = lane >> 4) holds W[16co + i][16cc + 8(qa & 1) + e][tap 2*slab + (qa >> 1)]."""
+    cout, cin, kh, kw = w.shape
+    nt = kh * kw
+    S = (nt + 1) // 2
+    wp = np.zeros((coutP, cinP, 2 * S), np.float32)
+    wp[:cout, :cin, :nt] = w.reshape(cout, cin, nt)
+    v = wp.reshape(coutP // 16, 16, cinP // 16, 2, 8, S, 2)          # [co][i][cc][half][e][slab][tp]
+    v = v.transpose(2, 0, 5, 6, 3, 1, 4)                                # [cc][co][slab][tp][half][i][e]
+    v = np.ascontiguousarray(v).reshape(cinP // 16, coutP // 16, S, 4, 16, 8)   # qa = 2*tp + half
+    h, m, l = split3(v)
+    out = np.stack([h, m, l], axis=3)                                   # [cc][co][slab][piece][qa][i][e]
+    return _bf16_bits_as_f32(out)
+
+
 def _frag(W: np.ndarray, R: int, S: int) -> np.ndarray:
     """16x16 block (rows 16R.., cols 16S..) of W as a lane-linear MFMA A fragment:
     [lane = 16*q + j][e] = W[16R + j][16S + 4q + e]; zero outside W."""
@@ -105,9 +147,24 @@ def _check_odd(ks):
             raise ValueError(f"kernel sizes must be odd and positive for 'same' padding, got {(kh, kw)}")
 
 
+ENGINES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+
+def default_engine() -> str:
+    """Conv arithmetic: ``f32`` exact fp32 MFMA; ``bf16x3`` three-piece bf16 split on the bf16
+    matrix pipe (fp32-equivalent accuracy, 2.7x fewer MFMA cycles); ``bf16`` plain bf16
+    operands with fp32 accumulation (BASELINE configs[2]).  Env ``FLOWTIMES_ENGINE``."""
+    import os
+
+    e = os.environ.get("FLOWTIMES_ENGINE", "bf16x3").strip().lower()
+    if e not in ENGINES:
+        raise ValueError(f"FLOWTIMES_ENGINE must be one of {sorted(ENGINES)}, got {e!r}")
+    return e
+
+
 def pack_inception(
     sd: Dict[str, np.ndarray], d_model: int, d_ff: int, kernel_set: Sequence[Tuple[int, int]],
-    ratio: float, act: str,
+    ratio: float, act: str, engine: str | None = None,
 ) -> Tuple[np.ndarray, FtnPlan]:
     """Fold + pack; returns (fp32 weight blob, FtnPlan with float offsets)."""
     ks = synth.parse_kernel_set(kernel_set)
@@ -118,6 +175,7 @@ def pack_inception(
     C, F = int(d_model), int(d_ff)
     CP, FP = _pad16(C), _pad16(F)
     plan = FtnPlan()
+    plan.engine = ENGINES[engine if engine is not None else default_engine()]
     plan.C, plan.CP, plan.F, plan.FP = C, CP, F, FP
     plan.act = 1 if act.lower() == "relu" else 0
     mid = synth.bottleneck_mid(C, F, ratio)
@@ -144,6 +202,8 @@ def pack_inception(
             plan.kh[j], plan.kw[j] = kh, kw
         CA = nk * MP
 
+        convs_bf = []
+
         def block(blk, cin, cout, cinP, coutP):
             W_in = np.zeros((CA, cinP)); b_in = np.zeros(CA)
             b_conv = np.zeros(CA)
@@ -164,6 +224,7 @@ def pack_inception(
                 W_out[:cout, j * MP: j * MP + mid] = Pk @ w3
                 b_out[:cout] += Pk @ sd[f"{blk}.paths.{j}.branch.2.bias"]
                 convs.append(_pack_conv(w2, MP, MP))
+                convs_bf.append(_pack_conv_bf(w2, MP, MP))
             return W_in, b_in, convs, b_conv, W_out, b_out
 
         W_in1, b_in1, convs1, b_conv1, W_out1, b_out1 = block("0", C, F, CP, FP)
@@ -201,6 +262,9 @@ def pack_inception(
         cf = _pack_cfrag(W_out1, Wr1, Wc, FP, nKM, nCP, n_ot)
         plan.w_cfrag = blob.add(cf)
         plan.cfrag_per_chunk, plan.n_hchunks = CHUNK_TILES * (nKM + nCP + n_ot), cf.shape[0]
+        for j in range(nk):
+            plan.w_convbf1[j] = blob.add(convs_bf[j])
+            plan.w_convbf2[j] = blob.add(convs_bf[nk + j])
     else:
         plan.mode = 1
         plan.MP, plan.nbr = 0, 1

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTN_ABI_VERSION 2
+#define FTN_ABI_VERSION 3
 #define FTN_KMAX 16      /* max period candidates / groups per block call        */
 #define FTN_MAXBR 8      /* max kernels in kernel_set                             */
 
@@ -84,6 +84,13 @@ typedef struct FtnPlan {
   int64_t w_cfrag;
   int32_t cfrag_per_chunk;  /* fragments (of 256 floats) per hidden chunk */
   int32_t n_hchunks;        /* ceil(FP / 32)                               */
+  /* bf16x3 conv engine (mode 0 only): per branch the k x k weights as three bf16 pieces in
+   * K=32 MFMA fragments, [cin/16][cout/16][slab = tap pair][piece][lane][8] (offsets in
+   * floats; the data are bf16).  engine: 0 = exact fp32 MFMA, 1 = bf16x3 split, 2 = plain bf16 */
+  int64_t w_convbf1[FTN_MAXBR];
+  int64_t w_convbf2[FTN_MAXBR];
+  int32_t engine;
+  int32_t reserved0;
   int64_t total_floats;
 } FtnPlan;
 

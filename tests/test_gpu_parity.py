@@ -33,10 +33,14 @@ def _hyper(case):
     return C, d_ff, [tuple(k) for k in h["kernel_set"]], h["ratio"], h["act"], h["d_ff_mult"] is None
 
 
-def _block(ftn, case, dev):
+ENGINES = ["f32", "bf16x3"]
+
+
+def _block(ftn, case, dev, engine=None):
     T = ftn.models.timesnet
     C, d_ff, ks, ratio, act, dff_none = _hyper(case)
     blk = T.TimesBlock(C, ks, 0.0, act, d_ff=None if dff_none else d_ff, bottleneck_ratio=ratio)
+    blk.engine = engine
     sd = ftn.synth.make_inception_params(C, d_ff, ks, ratio, case["seed"])
     blk.inception.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     return blk.eval().to(dev), {k: torch.from_numpy(v) for k, v in sd.items()}, ks, act
@@ -73,10 +77,11 @@ BLOCKS = ["b_tiny_min", "b_tiny_pipe", "b_c0_min", "b_c0_pipe", "b_c0_rect", "b_
           "b_odd_pipe", "b_c1_min", "b_c1_pipe", "b_c2_pipe_k5", "b_noise_pipe"]
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name", BLOCKS)
-def test_block_matches_reference(name, manifest, golden, ftn, dev):
+def test_block_matches_reference(name, engine, manifest, golden, ftn, dev):
     case, g = manifest[name], golden(name)
-    blk, _, _, _ = _block(ftn, case, dev)
+    blk, _, _, _ = _block(ftn, case, dev, engine)
     blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(case["K"], case["L"])
     with torch.inference_mode():
         y = blk(torch.from_numpy(g["x"]).to(dev))
@@ -106,12 +111,13 @@ class _Stub(torch.nn.Module):
 STUBS = ["s_dup", "s_mixed_pad", "s_448", "s_wide_rows", "s_p1"]
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name", STUBS)
-def test_stub_selector_matches_reference(name, manifest, golden, ftn, dev):
+def test_stub_selector_matches_reference(name, engine, manifest, golden, ftn, dev):
     """host grouping -> uploaded descriptor -> HIP conv path (reference tests inject selectors
     the same way, tests/test_times_block.py:93)"""
     case, g = manifest[name], golden(name)
-    blk, _, _, _ = _block(ftn, case, dev)
+    blk, _, _, _ = _block(ftn, case, dev, engine)
     object.__setattr__(blk, "period_selector", _Stub(g["periods"], g["amps"]))
     with torch.inference_mode():
         y = blk(torch.from_numpy(g["x"]).to(dev))
@@ -156,9 +162,10 @@ def test_lrtc_matches_reference(name, manifest, golden, ftn, dev):
     (4, 720, 128, 3, "pipeline", 14), (5, 200, 24, 4, "rect", 15), (3, 97, 5, 3, "wide1", 16),
     (32, 96, 16, 2, "minimal", 17),
 ])
-def test_block_matches_oracle_seeded(B, L, C, K, hyper, seed, ftn, dev):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_block_matches_oracle_seeded(B, L, C, K, hyper, seed, engine, ftn, dev):
     case = dict(hyper=hyper, C=C, seed=seed)
-    blk, P, ks, act = _block(ftn, case, dev)
+    blk, P, ks, act = _block(ftn, case, dev, engine)
     blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(K, L)
     x = torch.from_numpy(ftn.synth.make_input(B, L, C, seed=seed))
     y_ref, aux = orc.timesblock_forward(x, P, ks, act, K, L)
