@@ -30,6 +30,7 @@ import __graft_entry__ as ge  # noqa: E402
 
 STAGES = ["A_pw_in(k_pw)", "B_conv1(k_conv)", "C_chain(k_mlp)", "D_conv2(k_conv)", "EF_out(k_out)", "-"]
 FP32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+BF16_MFMA_PEAK_TF = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_16x16x32_bf16)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -54,6 +55,7 @@ def main() -> None:
     ap.add_argument("--d-model", type=int, default=64)
     ap.add_argument("--k-periods", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--act", default="gelu", help="diagnostic: activation (gelu = reference default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,7 +77,7 @@ def main() -> None:
     ks = [(3, 3), (5, 5), (7, 7)]
     ratio = 4.0
     params = pkg.synth.make_inception_params(C, F, ks, ratio, seed=0)
-    blk = T.TimesBlock(C, ks, 0.0, "gelu", d_ff=F, bottleneck_ratio=ratio)
+    blk = T.TimesBlock(C, ks, 0.0, args.act, d_ff=F, bottleneck_ratio=ratio)
     blk.inception.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     blk.period_selector = T.FFTPeriodSelector(K, L)
     blk = blk.eval().to(dev)
@@ -90,6 +92,25 @@ def main() -> None:
     else:
         step = lambda: blk(x)
         barrier = lambda: None
+
+    engine = blk.engine or pkg.pack.default_engine()
+    alt_ms = {}
+    if world == 1:
+        # the other conv/chain arithmetic, timed briefly for comparison (same weights, same input)
+        for alt in ("f32", "bf16x3"):
+            if alt == engine:
+                continue
+            blk.engine = alt
+            with torch.inference_mode():
+                for _ in range(3):
+                    blk(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    blk(x)
+                torch.cuda.synchronize()
+                alt_ms[alt] = (time.perf_counter() - t0) * 100.0
+        blk.engine = None
 
     with torch.inference_mode():
         for _ in range(args.warmup):
@@ -129,6 +150,20 @@ def main() -> None:
         macs = stage_macs(C, F, ks, ratio, pkg.pack)
         dom = int(np.argmax(stage_ms))
         flops_exec = 2.0 * macs[dom] * px
+        peak_tf = FP32_MFMA_PEAK_TF
+        if engine != "f32" and dom in (1, 2, 3):
+            # bf16 matrix pipe: count what the pipe executes (K padded to 32, 6 partial products
+            # per fp32 product for bf16x3, 1 for plain bf16) against the dense bf16 peak
+            nprod = 6 if engine == "bf16x3" else 1
+            mid = macs[1] // sum(kh * kw for kh, kw in ks)          # mid*mid
+            if dom == 2:
+                kpad = lambda v: (v + 31) // 32 * 32
+                nbm = len(ks) * int(round(mid ** 0.5))
+                mac_pad = kpad(nbm) * F + kpad(C) * F + F * (nbm + C)
+            else:
+                mac_pad = mid * sum((kh * kw + 1) // 2 * 2 for kh, kw in ks)
+            flops_exec = 2.0 * mac_pad * px * nprod
+            peak_tf = BF16_MFMA_PEAK_TF
         achieved = flops_exec / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
         nominal = 2.0 * pkg.pack.macs_per_pixel(C, F, ks, ratio) * px
         executed = 2.0 * pkg.pack.macs_per_pixel(C, F, ks, ratio, folded=True) * px
@@ -145,13 +180,18 @@ def main() -> None:
             "metric": "TimesBlock-forward series/sec (B=256 L=336 N=512)",
             "value": value, "unit": "series/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if engine == "f32" else ("f32 via bf16x3 split" if engine == "bf16x3" else "bf16"),
+            "data": "synthetic",
             "config": {"workload": f"timesblock_fwd B={B}/gpu L={L} N={NS} d_model={C} d_ff={F} kernels=3/5/7 "
-                                   f"ratio=4 k_periods={K} fp32 (BASELINE configs[2] shape, fp32 compute)",
+                                   f"ratio=4 k_periods={K}; arithmetic engine={engine} "
+                                   "(f32: exact fp32 MFMA; bf16x3: three bf16 pieces per fp32 value, six partial "
+                                   "products on the bf16 matrix pipe, fp32 accumulate, error <= an fp32 FMA chain; "
+                                   "same 1e-4 parity tests)",
+                       "engine": engine, "other_engine_ms_per_step": alt_ms,
                        "windows_per_s": world * B / (elapsed / args.steps), "periods": periods, "groups": G,
                        "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "kernel": STAGES[dom], "achieved": achieved, "peak": FP32_MFMA_PEAK_TF,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": STAGES[dom], "achieved": achieved, "peak": peak_tf,
+                         "unit": "TFLOP/s", "frac": achieved / peak_tf, "traffic": traffic,
                          "flops_per_launch": flops_exec, "avg_launch_ms": stage_ms[dom],
                          "stage_ms": dict(zip(STAGES, [round(v, 4) for v in stage_ms])),
                          "conv_path_ms": conv_ms,

@@ -25,6 +25,7 @@
 //   E+F k_out      y  = x + sum_g w[b,g] * (act(W_out2 m'_g + b) + r_g)[:L]
 // Single-conv mode (ratio 1) replaces A by a zero-padded copy of x, B/D by one
 // merged conv with proj folded in, and E by an elementwise epilogue.
+#include <stdlib.h>
 #include "ftn_common.h"
 
 #define NPXU 4  // 16-pixel units per wave in the pointwise / conv kernels
@@ -417,6 +418,249 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
           else *(f4*)(a.outA + (size_t)px[u].n * a.AC + 16 * o + 4 * q) = oacc[o][u];
         } else {
           const int ch = 16 * (o - a.n_oa) + 4 * q;
+          *(f4*)(a.outR + (size_t)px[u].n * CP + ch) = oacc[o][u] - load_x4<XVEC>(px[u].xrow, ch, a.C);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- stage C, bf16x3 engine
+// The same register-chained pointwise stage on the bf16 matrix pipe: every operand is three
+// bf16 pieces and every K=32 slab is the six-product chain of k_conv_bf.  Layer-1 inputs
+// (m: P3 rows written by the conv; x: split on load) are preloaded once; after the two
+// GELUs the fp32 hidden accumulators of a 32-channel chunk (two row tiles) are split into
+// pieces in registers and become the B operand of the output projection (the host packs
+// the projection's K order to match the accumulator lane map).  512-thread workgroups
+// (256 pixels) share each chunk's weight fragments, DMA-staged and double-buffered.
+struct MlpBfArgs {
+  const float* x;
+  const __bf16* m;       // P3 [N][KM/16][3][16]
+  const __bf16* cfrag;   // [n_hchunks][per_chunk][3][512]
+  const float* bo;
+  const float* br;
+  const float* bc;
+  __bf16* outA;          // P3 [N][AC/16][3][16]
+  float* outR;           // [N][CP]
+  const FtnDesc* desc;
+  int B, L, C, CP, FP, KM, AC;
+  int nsKM, nsCP;        // K=32 slabs of layer 1 / of the residual (each <= 2)
+  int n_oa, n_ot, n_hchunks, per_chunk;
+  unsigned long long* dbg; size_t dbg_cap;
+};
+
+template <int NS>
+__device__ __forceinline__ f4 chain_bf(const bf8 (&ap)[NS], const bf8 (&bp)[NS], f4 c) {
+  if (NS == 3) {
+    c = mfma_bf(ap[0], bp[2], c);
+    c = mfma_bf(ap[2], bp[0], c);
+    c = mfma_bf(ap[1], bp[1], c);
+    c = mfma_bf(ap[0], bp[1], c);
+    c = mfma_bf(ap[1], bp[0], c);
+  }
+  return mfma_bf(ap[0], bp[0], c);
+}
+
+// eight fp32 values -> NS bf16 pieces of 8
+template <int NS>
+__device__ __forceinline__ void split_pieces(const float (&v)[8], bf8 (&out)[NS]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    out[0][e] = h;
+    if (NS == 3) {
+      const float r1 = v[e] - (float)h;
+      const __bf16 m = (__bf16)r1;
+      out[1][e] = m;
+      out[2][e] = (__bf16)(r1 - (float)m);
+    }
+  }
+}
+
+template <int ACT, bool XVEC, int OTM, bool EXACT, int NS>
+__global__ __launch_bounds__(512) void k_mlp_bf(MlpBfArgs a) {
+  constexpr int NPX = 2;
+  extern __shared__ __attribute__((aligned(16))) char wlb[];
+  const FtnDesc* __restrict__ d = a.desc;
+  const int N = a.B * d->total_px;
+  stamp(a.dbg, a.dbg_cap, blockIdx.x, 0);
+  if ((int)(blockIdx.x * 8 * 16 * NPX) >= N) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int n0 = (blockIdx.x * 8 + wave) * (16 * NPX);
+  const bool active = n0 < N;
+  const int bufsz = a.per_chunk * 3 * 1024;
+  auto dma_chunk = [&](int hc, int buf) {
+    const __bf16* __restrict__ src = a.cfrag + (size_t)hc * a.per_chunk * 3 * 512;
+    for (int piece = wv; piece < a.per_chunk * 3; piece += 8)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(wlb + (size_t)buf * bufsz + (size_t)piece * 1024),
+                                       16, 0, 0);
+  };
+  dma_chunk(0, 0);
+  Px px[NPX];
+#pragma unroll
+  for (int u = 0; u < NPX; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
+  const int FP = a.FP, CP = a.CP, nht = FP >> 4;
+  const int nsKM = a.nsKM, nsCP = a.nsCP, n_ot = EXACT ? OTM : a.n_ot;
+  const int kmg = a.KM >> 4;                                  // 16-channel groups of m
+  // B operands that do not depend on the hidden chunk
+  bf8 mp[2][NPX][NS], xp[2][NPX][NS];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) {
+      const int grp = 2 * s + (qa >> 1);
+      const __bf16* __restrict__ src = a.m + ((size_t)px[u].n * kmg + (grp < kmg ? grp : 0)) * 48 + (qa & 1) * 8;
+#pragma unroll
+      for (int pz = 0; pz < NS; ++pz) {
+        bf8 v = *(const bf8*)(src + pz * 16);
+        if (!(s < nsKM && grp < kmg)) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
+        }
+        mp[s][u][pz] = v;
+      }
+      float xv[8];
+      const f4 x0 = s < nsCP ? load_x4<XVEC>(px[u].xrow, 32 * s + 8 * qa, a.C) : f4{0.f, 0.f, 0.f, 0.f};
+      const f4 x1 = s < nsCP ? load_x4<XVEC>(px[u].xrow, 32 * s + 8 * qa + 4, a.C) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xv[e] = x0[e]; xv[4 + e] = x1[e]; }
+      split_pieces<NS>(xv, xp[s][u]);
+    }
+  }
+  f4 oacc[OTM][NPX];
+#pragma unroll
+  for (int o = 0; o < OTM; ++o) {
+    f4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (o < n_ot) bv = *(const f4*)(a.bc + 16 * o + 4 * qa);
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) oacc[o][u] = bv;
+  }
+  __syncthreads();
+  stamp(a.dbg, a.dbg_cap, blockIdx.x, 1);
+  for (int hc = 0; hc < a.n_hchunks; ++hc) {
+    if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 2);
+    const char* __restrict__ wl = wlb + (size_t)(hc & 1) * bufsz + lane * 16;
+    // this chunk's biases first (ordinary loads), THEN the DMA of the next chunk: the other
+    // buffer was last read before the barrier that opened this chunk, and nothing below waits
+    // on vmcnt until the closing barrier, so the DMA has the whole chunk to land
+    f4 bo_t[2], br_t[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bo_t[t] = f4{0.f, 0.f, 0.f, 0.f};
+      br_t[t] = f4{0.f, 0.f, 0.f, 0.f};
+      if (active && hc * 2 + t < nht) {
+        bo_t[t] = *(const f4*)(a.bo + 16 * (hc * 2 + t) + 4 * qa);
+        br_t[t] = *(const f4*)(a.br + 16 * (hc * 2 + t) + 4 * qa);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (hc + 1 < a.n_hchunks) dma_chunk(hc + 1, (hc + 1) & 1);
+    if (active) {
+      // Statically scheduled chunk (KM <= 64, C <= 64: two K slabs each).  The 8 + 2*n_ot weight
+      // fragments are walked in LDS order with a one-step-ahead register prefetch, and the
+      // VALU work (GELU, piece splitting) of one row tile / pixel unit is placed in the same
+      // scheduling region as MFMAs that do not depend on it, so both pipes stay busy although
+      // the two waves of a SIMD run in lockstep between chunk barriers:
+      //   f0 f1: L1(t0) | f2 f3: L1(t1) + G1(t0) | f4 f5: R(t0) + G1(t1) | f6 f7: R(t1) + G2(t0)
+      //   G2(t1,u0) split(u0) | L2(u0) + G2(t1,u1) split(u1) | L2(u1)
+      f4 h[2][NPX];
+      bf8 hp[NPX][NS];
+      auto ldfrag = [&](int f, bf8 (&ap)[NS]) {
+#pragma unroll
+        for (int pz = 0; pz < NS; ++pz) ap[pz] = *(const bf8*)(wl + (size_t)(f * 3 + pz) * 1024);
+      };
+      auto gelu_u = [&](int t, int u, bool addbr) {
+        h[t][u] = act4<ACT>(h[t][u]);
+        if (addbr) h[t][u] += br_t[t];
+      };
+      auto split_u = [&](int u) {
+        float hv[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hv[e] = h[0][u][e]; hv[4 + e] = h[1][u][e]; }
+        split_pieces<NS>(hv, hp[u]);
+      };
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) h[t][u] = bo_t[t];
+      bf8 fa[NS], fb[NS];
+      ldfrag(0, fa);
+      // ---- L1(t0)
+      ldfrag(1, fb); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[0][u] = chain_bf<NS>(fa, mp[0][u], h[0][u]);
+      ldfrag(2, fa); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[0][u] = chain_bf<NS>(fb, mp[1][u], h[0][u]);
+      // ---- L1(t1) + G1(t0)
+      ldfrag(3, fb); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[1][u] = chain_bf<NS>(fa, mp[0][u], h[1][u]);
+      gelu_u(0, 0, true);
+      ldfrag(4, fa); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[1][u] = chain_bf<NS>(fb, mp[1][u], h[1][u]);
+      gelu_u(0, 1, true);
+      // ---- R(t0) + G1(t1)
+      ldfrag(5, fb); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[0][u] = chain_bf<NS>(fa, xp[0][u], h[0][u]);
+      gelu_u(1, 0, true);
+      ldfrag(6, fa); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[0][u] = chain_bf<NS>(fb, xp[1][u], h[0][u]);
+      gelu_u(1, 1, true);
+      // ---- R(t1) + G2(t0)
+      ldfrag(7, fb); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[1][u] = chain_bf<NS>(fa, xp[0][u], h[1][u]);
+      gelu_u(0, 0, false);
+      ldfrag(8, fa); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) h[1][u] = chain_bf<NS>(fb, xp[1][u], h[1][u]);
+      gelu_u(0, 1, false);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- G2(t1,u0), split(u0)   (the only VALU stretch without an MFMA partner)
+      gelu_u(1, 0, false);
+      split_u(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- L2(u0) + G2(t1,u1), split(u1): fragments f = 8 .. 8+n_ot-1, ping-pong fa/fb
+#pragma unroll
+      for (int o = 0; o < OTM; ++o) {
+        if (EXACT || o < n_ot) {
+          if (o & 1) { ldfrag(8 + (o + 1 < n_ot ? o + 1 : 0), fa); __builtin_amdgcn_sched_barrier(0); oacc[o][0] = chain_bf<NS>(fb, hp[0], oacc[o][0]); }
+          else       { ldfrag(8 + (o + 1 < n_ot ? o + 1 : 0), fb); __builtin_amdgcn_sched_barrier(0); oacc[o][0] = chain_bf<NS>(fa, hp[0], oacc[o][0]); }
+          if (o == 0) gelu_u(1, 1, false);
+          if (o == 1 || (n_ot == 1 && o == 0)) split_u(1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- L2(u1): the wrap-around prefetch above left fragment 8 in the next register set
+#pragma unroll
+      for (int o = 0; o < OTM; ++o) {
+        if (EXACT || o < n_ot) {
+          const bool odd = ((n_ot + o) & 1) != 0;
+          if (odd) { ldfrag(8 + (o + 1 < n_ot ? o + 1 : o), fa); __builtin_amdgcn_sched_barrier(0); oacc[o][1] = chain_bf<NS>(fb, hp[1], oacc[o][1]); }
+          else     { ldfrag(8 + (o + 1 < n_ot ? o + 1 : o), fb); __builtin_amdgcn_sched_barrier(0); oacc[o][1] = chain_bf<NS>(fa, hp[1], oacc[o][1]); }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  stamp(a.dbg, a.dbg_cap, blockIdx.x, 3);
+  if (!active) return;
+#pragma unroll
+  for (int o = 0; o < OTM; ++o) {
+    if (EXACT || o < n_ot) {
+#pragma unroll
+      for (int u = 0; u < NPX; ++u) {
+        if (!px[u].ok) continue;
+        if (o < a.n_oa) {
+          store_p3(a.outA + ((size_t)px[u].n * (a.AC >> 4) + o) * 48, qa, oacc[o][u]);
+        } else {
+          const int ch = 16 * (o - a.n_oa) + 4 * qa;
           *(f4*)(a.outR + (size_t)px[u].n * CP + ch) = oacc[o][u] - load_x4<XVEC>(px[u].xrow, ch, a.C);
         }
       }
@@ -1211,7 +1455,7 @@ static WsLayout ws_layout(const FtnPlan* pl, int B, int L, int max_groups) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   w.off0 = 0;
   w.off1 = al(w.off0 + N * w.c0 * (pl->engine != 0 && pl->mode == 0 ? 6 : 4));   // P3 = 6 bytes per value
-  w.off2 = al(w.off1 + N * w.c1 * 4);                 // R [N][CP]
+  w.off2 = al(w.off1 + N * w.c1 * (pl->engine != 0 && pl->mode == 0 ? 6 : 4));   // R [N][CP]
   w.off3 = al(w.off2 + N * pl->CP * 4);               // G [N][FP] (mode 1)
   w.total = pl->mode == 0 ? w.off3 : al(w.off3 + N * pl->FP * 4);
   return w;
@@ -1362,6 +1606,29 @@ static int launch_mlp(const MlpArgs& ma, bool xvec, long long Nmax, hipStream_t 
   return xvec ? launch_mlp_x<ACT, true>(ma, Nmax, st) : launch_mlp_x<ACT, false>(ma, Nmax, st);
 }
 
+template <int ACT, bool XVEC, int OTM, bool EXACT, int NS>
+static int launch_mlp_bf_t(MlpBfArgs ma, long long Nmax, hipStream_t st) {
+  ma.dbg = (g_stamp_which & 2) ? g_stamp_buf : nullptr; ma.dbg_cap = g_stamp_cap;
+  const size_t lds = (size_t)ma.per_chunk * 3 * 1024 * 2;
+  hipError_t e = hipFuncSetAttribute((const void*)k_mlp_bf<ACT, XVEC, OTM, EXACT, NS>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_bf): %s", hipGetErrorString(e)); return (int)e; }
+  const int nblk = (int)((Nmax + 255) / 256);
+  hipLaunchKernelGGL((k_mlp_bf<ACT, XVEC, OTM, EXACT, NS>), dim3(nblk), dim3(512), lds, st, ma);
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int ACT, int NS>
+static int launch_mlp_bf(const MlpBfArgs& ma, bool xvec, long long Nmax, hipStream_t st) {
+  if (ma.n_ot == 7) {
+    if (xvec) return launch_mlp_bf_t<ACT, true, 7, true, NS>(ma, Nmax, st);
+    return launch_mlp_bf_t<ACT, false, 7, true, NS>(ma, Nmax, st);
+  }
+  if (xvec) return launch_mlp_bf_t<ACT, true, 8, false, NS>(ma, Nmax, st);
+  return launch_mlp_bf_t<ACT, false, 8, false, NS>(ma, Nmax, st);
+}
+
 template <int ACT>
 static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, const float* wb, const FtnDesc* desc,
                      const float* wts, int max_groups, char* ws, hipStream_t st) {
@@ -1396,8 +1663,12 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     else if ((rc = launch_pw<ACT, true, 0>(pa, xvec, nblk_pw, st))) return rc;
     prof_mark(1, st);
     ConvBfArgs cb = {};
+    // stage C on the bf16 pipe too when the plan carries its fragments and the shapes fit
+    const int n_ot_c = CA / 16 + (pl->res2 ? CP / 16 : 0);
+    const bool mlp_bf = use_bf && pl->cfragbf_per_chunk > 0 && pl->res1 && pl->res2 && CA > 32 && CA <= 64 && CP > 32 && CP <= 64 &&
+                        n_ot_c <= 8 && (size_t)pl->cfragbf_per_chunk * 3 * 1024 * 2 <= 160 * 1024;
     if (use_bf) {
-      cb.in = (const __bf16*)buf0; cb.out = buf1; cb.out_p3 = 0; cb.bias = wb + pl->b_conv1; cb.desc = desc;
+      cb.in = (const __bf16*)buf0; cb.out = buf1; cb.out_p3 = mlp_bf ? 1 : 0; cb.bias = wb + pl->b_conv1; cb.desc = desc;
       cb.B = B; cb.INC = CA; cb.OUTC = CA; cb.nbr = pl->nbr; cb.cin = pl->MP; cb.cout = pl->MP;
       cb.in_stride_br = pl->MP / 16; cb.out_stride_br = pl->MP;
       for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf1[k]); cb.kh[k] = pl->kh[k]; cb.kw[k] = pl->kw[k]; }
@@ -1422,13 +1693,24 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ma.outA_p3 = use_bf ? 1 : 0;
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model/mid too large for v1", ma.n_ot); return -1; }
     if (ma.cfrag_per_chunk != MLP_HT * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
-    if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
+    if (mlp_bf) {
+      MlpBfArgs mb = {};
+      mb.x = x; mb.m = (const __bf16*)buf1; mb.cfrag = (const __bf16*)(wb + pl->w_cfragbf);
+      mb.bo = wb + pl->b_out1; mb.br = wb + pl->b_res1; mb.bc = wb + pl->b_c2;
+      mb.outA = (__bf16*)buf0; mb.outR = bufR; mb.desc = desc;
+      mb.B = B; mb.L = L; mb.C = C; mb.CP = CP; mb.FP = FP; mb.KM = CA; mb.AC = CA;
+      mb.nsKM = (CA + 31) / 32; mb.nsCP = (CP + 31) / 32;
+      mb.n_oa = CA / 16; mb.n_ot = n_ot_c; mb.n_hchunks = pl->n_hchunks; mb.per_chunk = pl->cfragbf_per_chunk;
+      if (mb.per_chunk != 2 * mb.nsKM + 2 * mb.nsCP + mb.n_ot) { ftn_set_error("plan/cfragbf layout mismatch"); return -1; }
+      if (nsplit == 3) { if ((rc = launch_mlp_bf<ACT, 3>(mb, xvec, Nmax, st))) return rc; }
+      else if ((rc = launch_mlp_bf<ACT, 1>(mb, xvec, Nmax, st))) return rc;
+    } else if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
     prof_mark(3, st);
     // D: m' = conv(a')
     ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
     if (use_bf) {
-      cb.bias = wb + pl->b_conv2;
+      cb.bias = wb + pl->b_conv2; cb.out_p3 = 0;
       for (int k = 0; k < pl->nbr; ++k) cb.W[k] = (const __bf16*)(wb + pl->w_convbf2[k]);
       if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st))) return rc;
     } else if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;

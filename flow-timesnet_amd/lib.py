@@ -13,7 +13,7 @@ from typing import Optional
 
 FTN_KMAX = 16
 FTN_MAXBR = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libflowtimes_hip.so"
@@ -59,7 +59,7 @@ class FtnPlan(C.Structure):
         ("w_c2", C.c_int64), ("b_c2", C.c_int64),
         ("w_cfrag", C.c_int64), ("cfrag_per_chunk", C.c_int32), ("n_hchunks", C.c_int32),
         ("w_convbf1", C.c_int64 * FTN_MAXBR), ("w_convbf2", C.c_int64 * FTN_MAXBR),
-        ("engine", C.c_int32), ("reserved0", C.c_int32),
+        ("engine", C.c_int32), ("cfragbf_per_chunk", C.c_int32), ("w_cfragbf", C.c_int64),
         ("total_floats", C.c_int64),
     ]
 

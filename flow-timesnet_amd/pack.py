@@ -141,6 +141,43 @@ def _pack_cfrag(W_out, W_res, W_c, FP: int, nKM: int, nCP: int, n_ot: int) -> np
     return out
 
 
+def _frag_bf(W, R: int, cols) -> np.ndarray:
+    """K=32 bf16 A fragment, three pieces: [piece][lane = 16*qa + i][e] = W[16R + i][cols[8*qa + e]]
+    (cols: 32 column indices, -1 = zero)."""
+    blk = np.zeros((16, 32), np.float32)
+    if W is not None:
+        r0 = 16 * R
+        rows = min(16, max(0, W.shape[0] - r0))
+        for k, c in enumerate(cols):
+            if c >= 0 and c < W.shape[1] and rows > 0:
+                blk[:rows, k] = W[r0:r0 + rows, c]
+    lanes = blk.reshape(16, 4, 8).transpose(1, 0, 2)              # [qa][i][e]
+    h, m, l = split3(lanes)
+    return np.stack([h, m, l], axis=0)                               # [piece][qa][i][e]
+
+
+def _pack_cfrag_bf(W_out, W_res, W_c, FP: int, nsKM: int, nsCP: int, n_ot: int) -> np.ndarray:
+    """Stage-C weights for the bf16x3 engine, per 32-channel hidden chunk:
+    [ W_out1: 2 tiles x nsKM slabs | W_res1: 2 tiles x nsCP slabs | W_c: n_ot tiles ] x 3 pieces,
+    1 KiB per piece.  Layer-2 columns follow the accumulator order of the hidden tile pair:
+    k = 8*qa + e -> hidden channel 32*hc + (e < 4 ? 4*qa + e : 16 + 4*qa + e - 4)."""
+    nch = (FP + 31) // 32
+    per = 2 * nsKM + 2 * nsCP + n_ot
+    out = np.zeros((nch, max(per, 1), 3, 4, 16, 8), np.float32)
+    for hc in range(nch):
+        k = 0
+        for t in range(2):
+            for s_ in range(nsKM):
+                out[hc, k] = _frag_bf(W_out, hc * 2 + t, list(range(32 * s_, 32 * s_ + 32))); k += 1
+        for t in range(2):
+            for s_ in range(nsCP):
+                out[hc, k] = _frag_bf(W_res, hc * 2 + t, list(range(32 * s_, 32 * s_ + 32))); k += 1
+        perm = [32 * hc + (4 * qa + e if e < 4 else 16 + 4 * qa + e - 4) for qa in range(4) for e in range(8)]
+        for o in range(n_ot):
+            out[hc, k] = _frag_bf(W_c, o, perm); k += 1
+    return _bf16_bits_as_f32(out)
+
+
 def _check_odd(ks):
     for kh, kw in ks:
         if kh % 2 == 0 or kw % 2 == 0 or kh < 1 or kw < 1:
@@ -265,6 +302,11 @@ def pack_inception(
         for j in range(nk):
             plan.w_convbf1[j] = blob.add(convs_bf[j])
             plan.w_convbf2[j] = blob.add(convs_bf[nk + j])
+        if plan.res1 and plan.res2:
+            nsKM, nsCP = (CA + 31) // 32, (CP + 31) // 32
+            plan.w_cfragbf = blob.add(_pack_cfrag_bf(W_out1.astype(np.float32), Wr1.astype(np.float32),
+                                                     Wc.astype(np.float32), FP, nsKM, nsCP, n_ot))
+            plan.cfragbf_per_chunk = 2 * nsKM + 2 * nsCP + n_ot
     else:
         plan.mode = 1
         plan.MP, plan.nbr = 0, 1

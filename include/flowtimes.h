@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTN_ABI_VERSION 3
+#define FTN_ABI_VERSION 4
 #define FTN_KMAX 16      /* max period candidates / groups per block call        */
 #define FTN_MAXBR 8      /* max kernels in kernel_set                             */
 
@@ -90,7 +90,10 @@ typedef struct FtnPlan {
   int64_t w_convbf1[FTN_MAXBR];
   int64_t w_convbf2[FTN_MAXBR];
   int32_t engine;
-  int32_t reserved0;
+  /* bf16x3 stage-C fragments per 32-channel hidden chunk (3 pieces x 1 KiB each; only when both
+   * res_proj convs exist): [chunk][w_out1 2 x ceil(KM/32) | w_res1 2 x ceil(CP/32) | w_c n_ot][piece] */
+  int32_t cfragbf_per_chunk;
+  int64_t w_cfragbf;
   int64_t total_floats;
 } FtnPlan;
 

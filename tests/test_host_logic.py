@@ -32,13 +32,13 @@ def test_library_exports_every_declared_symbol(ftn):
     assert declared == set(ftn.lib.EXPORTS), declared ^ set(ftn.lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ftn_abi_version() == 3
+    assert lib.ftn_abi_version() == 4
 
 
 def test_struct_sizes_match_header(ftn):
     # FtnDesc: 4 + 6*16 + 17 + 4*16 + 17 ints ; FtnPlan: 26 ints + 33 int64 + 2 ints + 1 int64
     assert ctypes.sizeof(ftn.lib.FtnDesc) == 4 * (4 + 6 * 16 + 17 + 4 * 16 + 17)
-    assert ctypes.sizeof(ftn.lib.FtnPlan) == 4 * 26 + 8 * 33 + 4 * 2 + 8 * 16 + 4 * 2 + 8
+    assert ctypes.sizeof(ftn.lib.FtnPlan) == 4 * 26 + 8 * 33 + 4 * 2 + 8 * 16 + 4 * 2 + 8 + 8
 
 
 @pytest.mark.parametrize("periods,L", [([24, 168, 7, 24, 0, 500], 336), ([4, 4, 8, 4], 25), ([47, 24, 2], 48),
