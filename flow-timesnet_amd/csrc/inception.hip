@@ -498,10 +498,17 @@ __global__ __launch_bounds__(512) void k_mlp_bf(MlpBfArgs a) {
                                        16, 0, 0);
   };
   dma_chunk(0, 0);
+  // biases of both hidden layers, zero-padded to whole chunks, in LDS behind the weight buffers
+  const int FPc = a.n_hchunks * 32;
+  float* __restrict__ bias_l = (float*)(wlb + 2 * (size_t)bufsz);
+  for (int i = threadIdx.x; i < 2 * FPc; i += 512) {
+    const int c = i < FPc ? i : i - FPc;
+    bias_l[i] = c < a.FP ? (i < FPc ? a.bo[c] : a.br[c]) : 0.f;
+  }
   Px px[NPX];
 #pragma unroll
   for (int u = 0; u < NPX; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
-  const int FP = a.FP, CP = a.CP, nht = FP >> 4;
+  const int CP = a.CP;
   const int nsKM = a.nsKM, nsCP = a.nsCP, n_ot = EXACT ? OTM : a.n_ot;
   const int kmg = a.KM >> 4;                                  // 16-channel groups of m
   // B operands that do not depend on the hidden chunk
@@ -542,21 +549,16 @@ __global__ __launch_bounds__(512) void k_mlp_bf(MlpBfArgs a) {
   for (int hc = 0; hc < a.n_hchunks; ++hc) {
     if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 2);
     const char* __restrict__ wl = wlb + (size_t)(hc & 1) * bufsz + lane * 16;
-    // this chunk's biases first (ordinary loads), THEN the DMA of the next chunk: the other
-    // buffer was last read before the barrier that opened this chunk, and nothing below waits
-    // on vmcnt until the closing barrier, so the DMA has the whole chunk to land
+    // request the next chunk right away: its buffer was last read before the barrier that
+    // opened this chunk, and nothing below waits on vmcnt until the closing barrier.  The
+    // biases come from LDS (staged once in the prologue), not from global memory.
+    if (hc + 1 < a.n_hchunks) dma_chunk(hc + 1, (hc + 1) & 1);
     f4 bo_t[2], br_t[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      bo_t[t] = f4{0.f, 0.f, 0.f, 0.f};
-      br_t[t] = f4{0.f, 0.f, 0.f, 0.f};
-      if (active && hc * 2 + t < nht) {
-        bo_t[t] = *(const f4*)(a.bo + 16 * (hc * 2 + t) + 4 * qa);
-        br_t[t] = *(const f4*)(a.br + 16 * (hc * 2 + t) + 4 * qa);
-      }
+      bo_t[t] = *(const f4*)(bias_l + 16 * (hc * 2 + t) + 4 * qa);
+      br_t[t] = *(const f4*)(bias_l + FPc + 16 * (hc * 2 + t) + 4 * qa);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (hc + 1 < a.n_hchunks) dma_chunk(hc + 1, (hc + 1) & 1);
     if (active) {
       // Statically scheduled chunk (KM <= 64, C <= 64: two K slabs each).  The 8 + 2*n_ot weight
       // fragments are walked in LDS order with a one-step-ahead register prefetch, and the
@@ -1609,7 +1611,7 @@ static int launch_mlp(const MlpArgs& ma, bool xvec, long long Nmax, hipStream_t 
 template <int ACT, bool XVEC, int OTM, bool EXACT, int NS>
 static int launch_mlp_bf_t(MlpBfArgs ma, long long Nmax, hipStream_t st) {
   ma.dbg = (g_stamp_which & 2) ? g_stamp_buf : nullptr; ma.dbg_cap = g_stamp_cap;
-  const size_t lds = (size_t)ma.per_chunk * 3 * 1024 * 2;
+  const size_t lds = (size_t)ma.per_chunk * 3 * 1024 * 2 + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)k_mlp_bf<ACT, XVEC, OTM, EXACT, NS>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_bf): %s", hipGetErrorString(e)); return (int)e; }
