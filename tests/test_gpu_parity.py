@@ -177,6 +177,47 @@ def test_block_matches_oracle_seeded(B, L, C, K, hyper, seed, engine, ftn, dev):
     np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL)
 
 
+# ---- awkward geometries through the stub path: multi-tile grids, ragged batch chunks,
+#      period L-1 (two very wide rows), period 1/2/3 (very tall grids), single batch row
+@pytest.mark.parametrize("engine", ENGINES)
+@pytest.mark.parametrize("B,L,C,hyper,periods", [
+    (5, 720, 64, "pipeline", [24, 719, 7]),          # 30x24 (2 row tiles), 2x719 (5 column tiles), 103x7
+    (7, 336, 64, "pipeline", [335, 2, 100]),         # 2x335, 168x2, 4x100 (pad 64): B not a multiple of 4
+    (1, 97, 64, "pipeline", [1, 3, 96]),             # period 1 (97x1), 33x3, 2x96 (pad 95)
+    (3, 400, 16, "pipeline", [64, 65, 399]),         # C=16: fp32 stage C beside the bf16 conv engine
+    (2, 336, 64, "minimal", [24, 168]),              # single-conv mode (always the fp32 engine)
+    (6, 1024, 64, "pipeline", [512, 16, 37]),        # long window
+])
+def test_awkward_geometries_match_oracle(B, L, C, hyper, periods, engine, ftn, dev):
+    case = dict(hyper=hyper, C=C, seed=21)
+    blk, P, ks, act = _block(ftn, case, dev, engine)
+    rs = np.random.RandomState(5)
+    amps = rs.standard_normal(size=(B, len(periods))).astype(np.float32)
+    object.__setattr__(blk, "period_selector", _Stub(periods, amps))
+    x = torch.from_numpy(ftn.synth.make_input(B, L, C, seed=9, planted=()))
+    y_ref, aux = orc.timesblock_forward(x, P, ks, act, 0, L, 1, periods=periods, amps=torch.from_numpy(amps))
+    with torch.inference_mode():
+        y = blk(x.to(dev))
+    assert blk._last_backend == "hip" and blk._last_group_count == len(aux.groups.periods)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_engines_agree_and_plain_bf16_is_close(ftn, dev):
+    """f32 and bf16x3 differ at rounding level; plain bf16 (BASELINE configs[2]) is a
+    reduced-precision path with its own tolerance."""
+    case = dict(hyper="pipeline", C=64, seed=4)
+    x = torch.from_numpy(ftn.synth.make_input(8, 336, 64, seed=4)).to(dev)
+    ys = {}
+    for eng in ("f32", "bf16x3", "bf16"):
+        blk, _, _, _ = _block(ftn, case, dev, eng)
+        blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(5, 336)
+        with torch.inference_mode():
+            ys[eng] = blk(x).cpu().numpy()
+    np.testing.assert_allclose(ys["bf16x3"], ys["f32"], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(ys["bf16"], ys["f32"], rtol=5e-2, atol=5e-2)
+    assert np.abs(ys["bf16"] - ys["f32"]).max() > 1e-5          # it really is a different arithmetic
+
+
 # ---- BASELINE full size (B=256 L=336 C=64): size-independent properties ---------
 def test_full_size_properties(ftn, dev):
     B, L, C, K = 256, 336, 64, 5
