@@ -61,12 +61,23 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # FTN_BENCH_FORCE_DIST=1 runs the multi-rank code path (RCCL process group, sharded runner,
+    # async all-gather) with a single rank: a rehearsal for boxes with one GPU
+    use_dist = world > 1 or os.environ.get("FTN_BENCH_FORCE_DIST") == "1"
+    # RCCL prints a version banner on stdout when its first communicator comes up; stdout must
+    # carry exactly one JSON line, so fd 1 points at stderr until the warm-up is over
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
     torch.cuda.set_device(dev)
 
     pkg = ge.load_package()
@@ -84,13 +95,32 @@ def main() -> None:
     x_host = pkg.synth.make_input(B, L, C, seed=rank)
     x = torch.from_numpy(x_host).to(dev)
 
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         runner = pkg.dist.ShardedTimesBlock(blk)
-        step = lambda: runner(x, gather=True)
+        pending = []
+
+        def step():
+            # the output all-gather of step i overlaps the compute of step i+1 (at most two in
+            # flight); every output is fully assembled on every rank before the clock stops
+            out, work = runner(x, gather="async")
+            pending.append((out, work))
+            if len(pending) > 2:
+                _, w0 = pending.pop(0)
+                if w0 is not None:
+                    w0.wait()
+            return out
+
+        def drain():
+            while pending:
+                _, w0 = pending.pop(0)
+                if w0 is not None:
+                    w0.wait()
+
         barrier = lambda: dist.barrier()
     else:
         step = lambda: blk(x)
+        drain = lambda: None
         barrier = lambda: None
 
     engine = blk.engine or pkg.pack.default_engine()
@@ -115,19 +145,24 @@ def main() -> None:
     with torch.inference_mode():
         for _ in range(args.warmup):
             y = step()
+        drain()
         torch.cuda.synchronize()
         barrier()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
         pkg.lib.check(lib.ftn_stage_timing(1), "ftn_stage_timing")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             y = step()
+        drain()
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
     assert blk._last_backend == "hip"
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -203,7 +238,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, params, ks, x_host, K, L, NS)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

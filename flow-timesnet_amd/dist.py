@@ -16,6 +16,7 @@ Everything else (top-k, grouping, convs, aggregation) is rank-local.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -23,19 +24,23 @@ import torch.distributed as dist
 from torch import nn
 
 
-def gather_batch(y_local: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather equal-sized shards along dim 0 -> ``[world*B_local, ...]`` on every rank."""
+def gather_batch(y_local: torch.Tensor, group=None, async_op: bool = False):
+    """All-gather equal-sized shards along dim 0 -> ``[world*B_local, ...]`` on every rank.
+
+    ``async_op=True`` returns ``(out, work)``: the collective runs on the backend's own stream
+    (RCCL over xGMI) and overlaps whatever the caller enqueues next; ``work.wait()`` makes the
+    current stream wait for it.  ``out`` must not be read before that."""
     world = dist.get_world_size(group)
-    if world == 1:
-        return y_local
+    if world == 1 and os.environ.get("FTN_BENCH_FORCE_DIST") != "1":
+        return (y_local, None) if async_op else y_local
     y_local = y_local.contiguous()
     out = y_local.new_empty((world * y_local.shape[0],) + tuple(y_local.shape[1:]))
     if y_local.is_cuda:
-        dist.all_gather_into_tensor(out, y_local, group=group)
+        work = dist.all_gather_into_tensor(out, y_local, group=group, async_op=async_op)
     else:  # gloo (CPU tests)
         parts = list(out.chunk(world, dim=0))
-        dist.all_gather(parts, y_local, group=group)
-    return out
+        work = dist.all_gather(parts, y_local, group=group, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 class ShardedTimesBlock(nn.Module):
@@ -53,13 +58,18 @@ class ShardedTimesBlock(nn.Module):
         if sel is None or not hasattr(sel, "shard_group"):
             raise ValueError("ShardedTimesBlock needs a block with a native FFTPeriodSelector")
 
-    def forward(self, x_local: torch.Tensor, gather: bool = True) -> torch.Tensor:
+    def forward(self, x_local: torch.Tensor, gather=True):
+        """``gather``: ``False`` -> this rank's rows; ``True`` -> the re-assembled global batch;
+        ``"async"`` -> ``(out, work)`` with the all-gather still in flight (see ``gather_batch``),
+        which lets a serving loop overlap step i's output exchange with step i+1's compute."""
         sel = self.block.period_selector
         grp = self.group if self.group is not None else dist.group.WORLD
         prev = sel.shard_group
-        sel.shard_group = grp if dist.get_world_size(grp) > 1 else None
+        sel.shard_group = grp if (dist.get_world_size(grp) > 1 or os.environ.get("FTN_BENCH_FORCE_DIST") == "1") else None
         try:
             y = self.block(x_local)
         finally:
             sel.shard_group = prev
+        if gather == "async":
+            return gather_batch(y, grp, async_op=True)
         return gather_batch(y, grp) if gather else y

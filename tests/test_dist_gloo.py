@@ -50,6 +50,9 @@ def _worker(rank, world, port, name, out_dir):
         with torch.no_grad():
             y = runner(shard, gather=True)
             y_local = runner(shard, gather=False)
+            y_async, work = runner(shard, gather="async")
+            work.wait()
+            assert torch.equal(y_async, y)
         assert blk.period_selector.shard_group is None          # restored after the call
         np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy())
         np.save(os.path.join(out_dir, f"p{rank}.npy"), blk.period_selector.last_selected_periods.numpy())
