@@ -157,22 +157,48 @@ __device__ __forceinline__ f4 mfma_bf(bf8 a, bf8 b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// Exact three-way split by truncation: hi = top 16 bits of x, r1 = x - hi (exact, <= 16
+// significant bits), mid = top 16 bits of r1, lo = r1 - mid (<= 8 significant bits, exactly a
+// bf16).  hi + mid + lo == x bit for bit, and packing two values' pieces into one dword is a
+// single v_perm_b32 of their upper halves - no v_cvt, no hazard nops.
+__device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {
+  // result = [hi_elem.bits[31:16] : lo_elem.bits[31:16]]
+  return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+__device__ __forceinline__ float trunc16(float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); }
+
+// n (even) fp32 values -> NS piece vectors; out[p] holds n bf16 = n/2 dwords
+template <int NS, int NV>
+__device__ __forceinline__ void split_trunc(const float (&v)[NV], unsigned (&out)[NS][NV / 2]) {
+  float r1[NV], r2[NV];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    if (NS == 3) {
+      r1[e] = v[e] - trunc16(v[e]);
+      r2[e] = r1[e] - trunc16(r1[e]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV / 2; ++k) {
+    out[0][k] = pack_hi16(v[2 * k], v[2 * k + 1]);
+    if (NS == 3) {
+      out[1][k] = pack_hi16(r1[2 * k], r1[2 * k + 1]);
+      out[2][k] = pack_hi16(r2[2 * k], r2[2 * k + 1]);
+    }
+  }
+}
+
 // "P3" activation layout: per pixel, per group of 16 channels: [hi 16][mid 16][lo 16] bf16
 // (96 bytes), so one K=32 MFMA slab reads 16 contiguous bytes per piece per lane.
 // Stores the 4 channels 4q..4q+3 of one group as three 8-byte pieces.
 __device__ __forceinline__ void store_p3(__bf16* __restrict__ grp, int q, f4 v) {
-  bf4 h, m, l;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const __bf16 hh = (__bf16)v[r];
-    const float r1 = v[r] - (float)hh;
-    const __bf16 mm = (__bf16)r1;
-    const float r2 = r1 - (float)mm;
-    h[r] = hh; m[r] = mm; l[r] = (__bf16)r2;
-  }
-  *(bf4*)(grp + 4 * q) = h;
-  *(bf4*)(grp + 16 + 4 * q) = m;
-  *(bf4*)(grp + 32 + 4 * q) = l;
+  const float vv[4] = {v[0], v[1], v[2], v[3]};
+  unsigned pc[3][2];
+  split_trunc<3, 4>(vv, pc);
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  *(u2*)(grp + 4 * q) = u2{pc[0][0], pc[0][1]};
+  *(u2*)(grp + 16 + 4 * q) = u2{pc[1][0], pc[1][1]};
+  *(u2*)(grp + 32 + 4 * q) = u2{pc[2][0], pc[2][1]};
 }
 
 template <int ACT>

@@ -461,19 +461,16 @@ __device__ __forceinline__ f4 chain_bf(const bf8 (&ap)[NS], const bf8 (&bp)[NS],
   return mfma_bf(ap[0], bp[0], c);
 }
 
-// eight fp32 values -> NS bf16 pieces of 8
+// eight fp32 values -> NS bf16 pieces of 8 (exact truncation split, ftn_common.h)
 template <int NS>
 __device__ __forceinline__ void split_pieces(const float (&v)[8], bf8 (&out)[NS]) {
+  unsigned pc[NS][4];
+  split_trunc<NS, 8>(v, pc);
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const __bf16 h = (__bf16)v[e];
-    out[0][e] = h;
-    if (NS == 3) {
-      const float r1 = v[e] - (float)h;
-      const __bf16 m = (__bf16)r1;
-      out[1][e] = m;
-      out[2][e] = (__bf16)(r1 - (float)m);
-    }
+  for (int p = 0; p < NS; ++p) {
+    const u4 w = {pc[p][0], pc[p][1], pc[p][2], pc[p][3]};
+    out[p] = __builtin_bit_cast(bf8, w);
   }
 }
 
