@@ -4,3 +4,4 @@ from .timesnet import (  # noqa: F401
     FFTPeriodSelector, InceptionBlock, InceptionBranch, LowRankTemporalContext, PeriodGrouper,
     PeriodGroupResult, TimesBlock,
 )
+from .shell import DataEmbedding, PositionalEmbedding, RMSNorm, TimesNet  # noqa: E402,F401

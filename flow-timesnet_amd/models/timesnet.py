@@ -532,3 +532,16 @@ class LowRankTemporalContext(nn.Module):
         ctx = torch.einsum("lr,bnr->bln", self._basis(length, coeff), coeff)
         ctx = (ctx - ctx.mean(dim=1, keepdim=True)) * self.scale.to(device=coeff.device, dtype=coeff.dtype)
         return ctx if add_to is None else add_to + ctx
+
+
+# The model shell (TimesNet, DataEmbedding, PositionalEmbedding, RMSNorm) lives in shell.py; it is
+# reachable from here as well so that ``from ...models.timesnet import TimesNet`` keeps working.
+_SHELL_NAMES = ("TimesNet", "DataEmbedding", "PositionalEmbedding", "RMSNorm")
+
+
+def __getattr__(name):
+    if name in _SHELL_NAMES:
+        from . import shell
+
+        return getattr(shell, name)
+    raise AttributeError(name)

@@ -80,6 +80,21 @@ SELECT_CASES = [
     ("sel_even_c", 2, 60, 4, 3, 60, 1, 5, (20, 5), 1.0),
 ]
 
+# Full model: reference TimesNet with non-zero heads; the whole state_dict is part
+# of the fixture (small models), so the GPU test needs nothing but the mirror.
+MODEL_CASES = {
+    "m_context": dict(cfg=dict(input_len=48, pred_len=12, d_model=16, d_ff=32, n_layers=2, k_periods=3,
+                               kernel_set=[(3, 3), (5, 5)], dropout=0.0, activation="gelu", mode="direct",
+                               bottleneck_ratio=2.0, use_checkpoint=False, id_embed_dim=8, static_proj_dim=8,
+                               use_zero_mean_context=True, context_rank=4, context_scale=0.05),
+                      B=3, N=5, static=6, ids=[4, 0, 2, 7, 1], marks=0, extra_t=0),
+    "m_pipeline": dict(cfg=dict(input_len=96, pred_len=24, d_model=64, d_ff=256, n_layers=2, k_periods=3,
+                                kernel_set=[(3, 3), (5, 5), (7, 7)], dropout=0.0, activation="gelu", mode="direct",
+                                bottleneck_ratio=4.0, use_checkpoint=True, id_embed_dim=4, min_period_threshold=2,
+                                use_zero_mean_context=True, context_rank=16, context_scale=0.05),
+                       B=4, N=8, static=0, ids=None, marks=2, extra_t=5),
+}
+
 LRTC_CASES = [("lrtc_a", 2, 24, 5, 4, 0.01, 0), ("lrtc_b", 3, 336, 7, 16, 0.5, 1), ("lrtc_c", 1, 150, 3, 1, -1.25, 2)]
 
 
@@ -182,6 +197,49 @@ def main() -> None:
                                 basis=mod._cached_basis.numpy())
             manifest["cases"][name] = dict(kind="lrtc", B=B, L=L, N=N, R=R, scale=scale, seed=seed)
             print(name, ctx.shape)
+
+        from timesnet_forecast.models.timesnet import TimesNet  # type: ignore
+        for name, mc in MODEL_CASES.items():
+            cfg = mc["cfg"]
+            B, N = mc["B"], mc["N"]
+            L = cfg["input_len"] + mc["extra_t"]
+            rs = np.random.RandomState(77)
+            t = np.arange(L, dtype=np.float64).reshape(1, L, 1)
+            x = (rs.standard_normal((B, L, N)) + 2.0 * np.sin(2 * np.pi * t / 12.0)
+                 + np.sin(2 * np.pi * t / 8.0 + rs.uniform(0, 6.28, (B, 1, N)))).astype(np.float32)
+            kw, arrs = {}, {"x": x}
+            if mc["static"]:
+                arrs["series_static"] = rs.standard_normal((N, mc["static"])).astype(np.float32)
+                kw["series_static"] = torch.from_numpy(arrs["series_static"])
+            if mc["ids"] is not None:
+                arrs["series_ids"] = np.asarray(mc["ids"], dtype=np.int64)
+                kw["series_ids"] = torch.from_numpy(arrs["series_ids"])
+            if mc["marks"]:
+                arrs["x_mark"] = rs.standard_normal((B, L, mc["marks"])).astype(np.float32)
+                kw["x_mark"] = torch.from_numpy(arrs["x_mark"])
+            torch.manual_seed(0)
+            model = TimesNet(**cfg).eval()
+            model(torch.from_numpy(x), **kw)
+            gen = torch.Generator().manual_seed(5)
+            for prm in model.parameters():
+                if float(prm.detach().abs().sum()) == 0.0:
+                    prm.copy_(0.1 * torch.randn(prm.shape, generator=gen))
+            # block weights come from the seeded generator (seed 100 + layer), not from the fixture
+            d_ff = cfg["d_ff"] if cfg.get("d_ff") else cfg["d_model"]
+            for li, blk in enumerate(model.blocks):
+                prm = synth.make_inception_params(cfg["d_model"], d_ff, cfg["kernel_set"],
+                                                  cfg.get("bottleneck_ratio", 1.0), seed=100 + li)
+                blk.inception.load_state_dict({k: torch.from_numpy(v) for k, v in prm.items()}, strict=True)
+            rate, disp = model(torch.from_numpy(x), **kw)
+            for k, v in model.state_dict().items():
+                if not k.startswith("blocks."):
+                    arrs["sd::" + k] = v.numpy()
+            arrs["rate"], arrs["dispersion"] = rate.numpy(), disp.numpy()
+            arrs["periods"] = model.period_selector.last_selected_periods.numpy()
+            np.savez_compressed(HERE / f"{name}.npz", **arrs)
+            manifest["cases"][name] = dict(kind="model", cfg={k: (list(map(list, v)) if k == "kernel_set" else v)
+                                                               for k, v in cfg.items()})
+            print(name, rate.shape, "last-layer periods", arrs["periods"].tolist())
 
     (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
     total = sum(p.stat().st_size for p in HERE.glob("*.npz"))

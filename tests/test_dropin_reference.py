@@ -68,3 +68,73 @@ def test_mirrors_drop_into_reference_timesnet(ftn, monkeypatch):
     assert all(b._period_calls >= 1 and b._last_backend == "torch" for b in swapped.blocks)
     torch.testing.assert_close(rate, want_rate, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(disp, want_disp, rtol=1e-5, atol=1e-6)
+
+
+# ---- the full model shell mirror (flow-timesnet_amd/models/shell.py) vs the reference TimesNet ----
+SHELL_CASES = {
+    "plain": (dict(input_len=24, pred_len=6, d_model=8, d_ff=16, n_layers=1, k_periods=2, kernel_set=[(3, 3)],
+                   dropout=0.0, activation="gelu", mode="direct", use_checkpoint=False, id_embed_dim=0), {}),
+    "context": (dict(CFG), dict(static=True, ids=True)),
+    "marks_layer": (dict(input_len=32, pred_len=8, d_model=12, d_ff=None, n_layers=2, k_periods=3,
+                         kernel_set=[(3, 3), (5, 5)], dropout=0.0, activation="relu", mode="direct",
+                         bottleneck_ratio=1.0, embed_norm_mode="layer", id_embed_dim=4, min_period_threshold=3),
+                    dict(marks=3, ids=True)),
+    "rms_recursive": (dict(input_len=30, pred_len=5, d_model=8, d_ff=24, n_layers=1, k_periods=2,
+                           kernel_set=[3, 5], dropout=0.0, activation="gelu", mode="recursive",
+                           bottleneck_ratio=3.0, embed_norm_mode="rms", id_embed_dim=6,
+                           use_constant_context_bias=True, use_late_bias_head=True), dict(ids=True, longer=7)),
+    "none_sigma_vec": (dict(input_len=20, pred_len=4, d_model=8, n_layers=1, k_periods=1, kernel_set=[(3, 3)],
+                            dropout=0.0, activation="gelu", mode="direct", use_embedding_norm=False,
+                            min_sigma_vector=[0.1, 0.2, 0.3, 0.4], static_proj_dim=None, static_layernorm=False,
+                            id_embed_dim=0, use_late_bias_head=False), dict(static=True, n=4)),
+}
+
+
+@pytest.mark.parametrize("name", list(SHELL_CASES))
+def test_timesnet_shell_mirror_matches_reference(name, ftn):
+    ref = _ref_module()
+    cfg, opt = SHELL_CASES[name]
+    N = opt.get("n", 5)
+    L = cfg["input_len"] + opt.get("longer", 0)
+    B = 3
+    g = torch.Generator().manual_seed(3)
+    t = torch.arange(L, dtype=torch.float32).view(1, L, 1)
+    x = torch.randn(B, L, N, generator=g) + 2.0 * torch.sin(2 * torch.pi * t / 8.0)
+    kw = {}
+    if opt.get("static"):
+        kw["series_static"] = torch.randn(N, 3, generator=g)
+    if opt.get("ids"):
+        kw["series_ids"] = torch.tensor([4, 0, 2, 7, 1][:N])
+    if opt.get("marks"):
+        kw["x_mark"] = torch.randn(B, L, opt["marks"], generator=g)
+    with torch.no_grad():
+        torch.manual_seed(0)
+        want = ref.TimesNet(**cfg).eval()
+        want(x, **kw)
+        for p in want.parameters():                      # wake up the zero-initialised heads
+            if float(p.detach().abs().sum()) == 0.0:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        rate_w, disp_w = want(x, **kw)
+        torch.manual_seed(1)
+        mine = ftn.models.TimesNet(**cfg).eval()
+        mine(x, **kw)
+        assert set(mine.state_dict().keys()) == set(want.state_dict().keys())
+        assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == \
+               {k: tuple(v.shape) for k, v in want.state_dict().items()}
+        mine.load_state_dict(want.state_dict(), strict=True)
+        rate, disp = mine(x, **kw)
+    assert mine.period_selector.last_selected_periods.tolist() == want.period_selector.last_selected_periods.tolist()
+    torch.testing.assert_close(rate, rate_w, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(disp, disp_w, rtol=1e-5, atol=1e-6)
+    # the freshly built mirror starts in the reference's initial state too (zero heads, gate values)
+    torch.manual_seed(0)
+    a = ref.TimesNet(**cfg).eval()
+    torch.manual_seed(0)
+    b = ftn.models.TimesNet(**cfg).eval()
+    with torch.no_grad():
+        ra, da = a(x, **kw)
+        b(x, **kw)
+        b.load_state_dict(a.state_dict(), strict=True)
+        rb, db = b(x, **kw)
+    torch.testing.assert_close(rb, ra, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(db, da, rtol=1e-5, atol=1e-6)

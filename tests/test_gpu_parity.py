@@ -260,3 +260,39 @@ def test_half_precision_input_roundtrip(ftn, dev):
     assert y16.dtype == torch.bfloat16
     assert next(blk.inception.parameters()).dtype == torch.float32
     np.testing.assert_allclose(y16.float().cpu().numpy(), y32.cpu().numpy(), rtol=0.05, atol=0.1)
+
+
+# ---- full model shell: mirror TimesNet with HIP blocks + HIP LRTC vs the reference ----
+def _model_from_fixture(ftn, case, g, dev):
+    cfg = dict(case["cfg"])
+    cfg["kernel_set"] = [tuple(k) for k in cfg["kernel_set"]]
+    model = ftn.models.TimesNet(**cfg).eval()
+    kw = {}
+    for key in ("series_static", "series_ids", "x_mark"):
+        if key in g:
+            kw[key] = torch.from_numpy(g[key])
+    with torch.no_grad():
+        model(torch.from_numpy(g["x"]), **kw)                     # materialise lazy layers on CPU
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    d_ff = cfg["d_ff"] if cfg.get("d_ff") else cfg["d_model"]
+    for li in range(cfg["n_layers"]):
+        prm = ftn.synth.make_inception_params(cfg["d_model"], d_ff, cfg["kernel_set"],
+                                              cfg.get("bottleneck_ratio", 1.0), seed=100 + li)
+        for k, v in prm.items():
+            sd[f"blocks.{li}.inception.{k}"] = torch.from_numpy(v)
+    model.load_state_dict(sd, strict=True)
+    return model.to(dev), {k: v.to(dev) for k, v in kw.items()}
+
+
+@pytest.mark.parametrize("name", ["m_context", "m_pipeline"])
+def test_full_model_matches_reference(name, manifest, golden, ftn, dev):
+    case, g = manifest[name], golden(name)
+    model, kw = _model_from_fixture(ftn, case, g, dev)
+    with torch.inference_mode():
+        rate, disp = model(torch.from_numpy(g["x"]).to(dev), **kw)
+    assert all(b._last_backend == "hip" for b in model.blocks)
+    if model.temporal_context is not None:
+        assert model.temporal_context._last_backend == "hip"
+    assert model.period_selector.last_selected_periods.tolist() == g["periods"].tolist()
+    np.testing.assert_allclose(rate.cpu().numpy(), g["rate"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(disp.cpu().numpy(), g["dispersion"], rtol=RTOL, atol=ATOL)

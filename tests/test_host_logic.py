@@ -254,3 +254,16 @@ def test_stub_selector_and_custom_inception_torch_backend(ftn):
     object.__setattr__(blk2, "period_selector", Stub([0, -1], [1.0, 1.0]))
     x = torch.randn(2, 5, 2)
     assert torch.equal(blk2(x), x)
+
+
+@pytest.mark.parametrize("name", ["m_context", "m_pipeline"])
+def test_full_model_mirror_cpu_matches_reference(name, manifest, golden, ftn):
+    """TimesNet shell mirror (torch backend on CPU) against the reference's golden outputs."""
+    from test_gpu_parity import _model_from_fixture
+    case, g = manifest[name], golden(name)
+    model, kw = _model_from_fixture(ftn, case, g, torch.device("cpu"))
+    with torch.no_grad():
+        rate, disp = model(torch.from_numpy(g["x"]), **kw)
+    assert model.period_selector.last_selected_periods.tolist() == g["periods"].tolist()
+    np.testing.assert_allclose(rate.numpy(), g["rate"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(disp.numpy(), g["dispersion"], rtol=1e-5, atol=1e-6)
