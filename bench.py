@@ -235,6 +235,7 @@ def main() -> None:
         }
         if world == 1:
             out["lrtc"] = lrtc_bench(pkg, dev, B, L, NS)
+            out["model_forward"] = model_bench(pkg, dev, B, L, NS, C, ks, ratio, K)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, params, ks, x_host, K, L, NS)
         print(json.dumps(out), flush=True)
@@ -267,6 +268,37 @@ def lrtc_bench(pkg, dev, B, L, N, R=16, iters=20):
                          "frac_hbm_peak": nbytes / ms / 1e6 / HBM_PEAK_GBS}
     res["shape"] = f"coeff[{B},{N},{R}] -> ctx[{B},{L},{N}] fp32"
     return res
+
+
+def model_bench(pkg, dev, B, L, N, d_model, ks, ratio, K, H=96, layers=3, R=16, iters=10):
+    """P2 of SURVEY §8(d): the whole TimesNet.forward [B,T,N] -> [B,H,N] (shell mirror: torch
+    ops for embedding / LayerNorm / heads, HIP kernels for the blocks and the LRTC), random
+    non-zero heads, static features + ids so the context path is live.  Extra, not `value`."""
+    model = pkg.models.TimesNet(input_len=L, pred_len=H, d_model=d_model, d_ff=4 * d_model, n_layers=layers,
+                                k_periods=K, kernel_set=ks, dropout=0.0, activation="gelu", mode="direct",
+                                bottleneck_ratio=ratio, use_checkpoint=True, id_embed_dim=32,
+                                use_zero_mean_context=True, context_rank=R).eval()
+    x = torch.from_numpy(pkg.synth.make_input(B, L, N, seed=7)).to(dev)
+    g = torch.Generator().manual_seed(0)
+    model.to(dev)
+    with torch.no_grad():
+        model(x[:2])                       # lazy build
+        for p in model.parameters():
+            if float(p.detach().abs().sum()) == 0.0:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g).to(p.device))
+    with torch.inference_mode():
+        for _ in range(2):
+            model(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            model(x)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return {"ms": ms, "series_per_s": B * N / (ms * 1e-3), "windows_per_s": B / (ms * 1e-3),
+            "config": f"TimesNet B={B} L={L}->H={H} N={N} d_model={d_model} d_ff={4 * d_model} layers={layers} "
+                      f"k={K} context_rank={R} id_embed=32 (reference CPU, 8 vCPU, survey: 3655 ms)"}
 
 
 def cpu_baseline(pkg, params, ks, x_host, K, L, NS):

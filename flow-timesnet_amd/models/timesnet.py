@@ -332,7 +332,9 @@ class TimesBlock(nn.Module):
 
         params = list(self.inception.parameters())
         engine = getattr(self, "engine", None) or pack.default_engine()
-        key = (str(device), engine) + tuple((p.data_ptr(), p._version) for p in params)
+        # inference tensors (lazy build under torch.inference_mode) carry no version counter
+        key = (str(device), engine) + tuple(
+            (p.data_ptr(), -1 if p.is_inference() else p._version) for p in params)
         if self._pack_key != key:
             sd = {k: v.detach().float().cpu().numpy() for k, v in self.inception.state_dict().items()}
             blob, plan = pack.pack_inception(sd, self.d_model, self.d_ff, self._kernel_spec,

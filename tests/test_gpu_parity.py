@@ -296,3 +296,20 @@ def test_full_model_matches_reference(name, manifest, golden, ftn, dev):
     assert model.period_selector.last_selected_periods.tolist() == g["periods"].tolist()
     np.testing.assert_allclose(rate.cpu().numpy(), g["rate"], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(disp.cpu().numpy(), g["dispersion"], rtol=RTOL, atol=ATOL)
+
+
+def test_lazy_build_under_inference_mode(ftn, dev):
+    """Parameters created by the lazy build inside torch.inference_mode are inference tensors (no
+    version counter); the packed-weight cache must cope and the HIP path must still be the one used."""
+    T = ftn.models.timesnet
+    blk = T.TimesBlock(None, [3, 5], 0.0, "gelu", d_ff=None, bottleneck_ratio=2.0).eval()
+    blk.period_selector = T.FFTPeriodSelector(3, 48)
+    x = torch.from_numpy(ftn.synth.make_input(4, 48, 32, seed=3, planted=(12, 8, 6))).to(dev)
+    with torch.inference_mode():
+        y1 = blk(x)
+        y2 = blk(x)
+    assert blk._last_backend == "hip"
+    assert torch.equal(y1, y2)
+    P = {k: v.detach().cpu() for k, v in blk.inception.state_dict().items()}
+    ref, _ = orc.timesblock_forward(x.cpu(), P, [(3, 3), (5, 5)], "gelu", 3, 48, 1)
+    np.testing.assert_allclose(y1.cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
