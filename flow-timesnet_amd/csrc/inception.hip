@@ -1156,7 +1156,92 @@ struct OutArgs {
   const float* wts;      // [B][FTN_KMAX]
   const FtnDesc* desc;
   int B, L, C, CP, KM;
+  const float* ln_g;     // optional fused epilogue (FAST path): y = LayerNorm_C(x + ((x + comb) - x)), the
+  const float* ln_b;     // per-block residual + shared LayerNorm of TimesNet.forward (reference :2050-2058)
+  float ln_eps;
 };
+
+// LayerNorm over the channel axis of an MFMA D-layout tile set: v[o][u][r] is channel 16o+4q+r of the
+// pixel (u, lane&15); the four q lane-groups of a pixel are combined with two xor-shuffles.
+// Two-pass (mean, then centred sum of squares), biased variance, as nn.LayerNorm.
+template <int NO, int NPX>
+__device__ __forceinline__ void ln_tiles(f4 (&v)[NO][NPX], int n_ot, int C, int q, const float* __restrict__ g,
+                                         const float* __restrict__ b, float eps) {
+  const float inv = 1.0f / (float)C;
+#pragma unroll
+  for (int u = 0; u < NPX; ++u) {
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (o < n_ot && 16 * o + 4 * q + r < C) s += v[o][u][r];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mean = s * inv;
+    float ss = 0.f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (o < n_ot && 16 * o + 4 * q + r < C) {
+          const float dv = v[o][u][r] - mean;
+          ss += dv * dv;
+        }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    const float rstd = 1.0f / sqrtf(ss * inv + eps);
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (o < n_ot && 16 * o + 4 * q + r < C) {
+          const int ch = 16 * o + 4 * q + r;
+          v[o][u][r] = (v[o][u][r] - mean) * rstd * g[ch] + b[ch];
+        }
+  }
+}
+
+// Standalone form of the same epilogue for the shapes k_out does not fuse (d_model > 64) and for
+// blocks that return x unchanged: out = LayerNorm_C(x + (nw - x)); one wave per row, in place allowed.
+__global__ __launch_bounds__(256) void k_resid_ln(const float* __restrict__ x, const float* nw, float* out,
+                                                  const float* __restrict__ g, const float* __restrict__ b,
+                                                  float eps, long long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  const float* nr = nw + row * C;
+  float* orow = out + row * C;
+  constexpr int MAXV = 8;                      // channels cached in registers: C <= 512; beyond that re-read
+  float v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = 0.f;
+    if (c < C) { const float xv = xr[c]; v[i] = xv + (nr[c] - xv); s += v[i]; }
+  }
+  for (int c = lane + 64 * MAXV; c < C; c += 64) { const float xv = xr[c]; s += xv + (nr[c] - xv); }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
+  const float mean = s / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (lane + 64 * i < C) { const float dv = v[i] - mean; ss += dv * dv; }
+  for (int c = lane + 64 * MAXV; c < C; c += 64) { const float xv = xr[c]; const float dv = xv + (nr[c] - xv) - mean; ss += dv * dv; }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) ss += __shfl_xor(ss, m);
+  const float rstd = 1.0f / sqrtf(ss / (float)C + eps);
+  // the tail (C > 512) must be produced before the cached part overwrites an in-place row
+  for (int c = lane + 64 * MAXV; c < C; c += 64) { const float xv = xr[c]; orow[c] = (xv + (nr[c] - xv) - mean) * rstd * g[c] + b[c]; }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) orow[c] = (v[i] - mean) * rstd * g[c] + b[c];
+  }
+}
 
 // Fast path (FAST): K <= 48 and <= 4 output tiles (d_model <= 64, nbr*mid <= 48): the 12
 // weight fragments are group-independent and live in registers; per group the wave only
@@ -1242,6 +1327,28 @@ __global__ __launch_bounds__(256) void k_out(OutArgs a) {
 #pragma unroll
         for (int u = 0; u < NPX; ++u) mc[s][u] = mn[s][u];
     }
+    const bool ln = a.ln_g != nullptr;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o < n_ot) {
+#pragma unroll
+        for (int u = 0; u < NPX; ++u) {
+          const int ch = 16 * o + 4 * q;
+          const size_t e0 = ((size_t)bb[u] * a.L + tt[u]) * a.C + ch;
+          f4 xv = {0.f, 0.f, 0.f, 0.f};
+          if (XVEC) {
+            if (ch < a.C) xv = *(const f4*)(a.x + e0);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (ch + r < a.C) xv[r] = a.x[e0 + r];
+          }
+          const f4 nv = xv + yacc[o][u];
+          yacc[o][u] = ln ? xv + (nv - xv) : nv;
+        }
+      }
+    }
+    if (ln) ln_tiles<4, NPX>(yacc, n_ot, a.C, q, a.ln_g, a.ln_b, a.ln_eps);
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       if (o < n_ot) {
@@ -1251,11 +1358,11 @@ __global__ __launch_bounds__(256) void k_out(OutArgs a) {
           const int ch = 16 * o + 4 * q;
           const size_t e0 = ((size_t)bb[u] * a.L + tt[u]) * a.C + ch;
           if (XVEC) {
-            if (ch < a.C) *(f4*)(a.y + e0) = *(const f4*)(a.x + e0) + yacc[o][u];
+            if (ch < a.C) *(f4*)(a.y + e0) = yacc[o][u];
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (ch + r < a.C) a.y[e0 + r] = a.x[e0 + r] + yacc[o][u][r];
+              if (ch + r < a.C) a.y[e0 + r] = yacc[o][u][r];
           }
         }
       }
@@ -1630,7 +1737,8 @@ static int launch_mlp_bf(const MlpBfArgs& ma, bool xvec, long long Nmax, hipStre
 
 template <int ACT>
 static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, const float* wb, const FtnDesc* desc,
-                     const float* wts, int max_groups, char* ws, hipStream_t st) {
+                     const float* wts, int max_groups, char* ws, hipStream_t st, const float* ln_g, const float* ln_b,
+                     float ln_eps) {
   const WsLayout wl = ws_layout(pl, B, L, max_groups);
   float* buf0 = (float*)(ws + wl.off0);
   float* buf1 = (float*)(ws + wl.off1);
@@ -1719,6 +1827,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     oa.x = x; oa.y = y; oa.m = buf1; oa.R = bufR; oa.W = wb + pl->w_out2; oa.bias = wb + pl->b_out2; oa.wts = wts;
     oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CA;
     const bool fast = CA <= 48 && CP <= 64;
+    if (fast) { oa.ln_g = ln_g; oa.ln_b = ln_b; oa.ln_eps = ln_eps; ln_g = nullptr; }   // fused epilogue
     if (xvec && yvec && fast) hipLaunchKernelGGL((k_out<ACT, true, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
     else if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
     else if (fast) hipLaunchKernelGGL((k_out<ACT, false, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
@@ -1765,14 +1874,20 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     FTN_CHECK_LAUNCH();
     prof_mark(5, st);
   }
+  if (ln_g) {                                                   // not fused above: in-place row pass over y
+    const long long rows = (long long)B * L;
+    hipLaunchKernelGGL(k_resid_ln, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, y, y, ln_g, ln_b, ln_eps, rows, C);
+    FTN_CHECK_LAUNCH();
+  }
   prof_mark(6, st);
   if (g_prof.on && g_prof.calls < FTN_PROF_CALLS) ++g_prof.calls;
   return 0;
 }
 
-extern "C" int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
-                                      const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                                      int max_groups, void* ws_dev, size_t ws_bytes, void* stream) {
+static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
+                           const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev, int max_groups,
+                           void* ws_dev, size_t ws_bytes, void* stream, const float* ln_g, const float* ln_b,
+                           float ln_eps) {
   FTN_CHECK_ARG(x_dev && y_dev && plan && wblob_dev && desc_dev && weights_dev && ws_dev,
                 "ftn_timesblock_forward: null pointer");
   FTN_CHECK_ARG(B >= 1 && B <= 65535 && L >= 2, "ftn_timesblock_forward: bad shape B=%d L=%d", B, L);
@@ -1789,7 +1904,34 @@ extern "C" int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, i
                 "ftn_timesblock_forward: workspace/weights must be 256/16-byte aligned");
   if (plan->act == 1)
     return forward_t<1>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, (char*)ws_dev,
-                        (hipStream_t)stream);
+                        (hipStream_t)stream, ln_g, ln_b, ln_eps);
   return forward_t<0>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, (char*)ws_dev,
-                      (hipStream_t)stream);
+                      (hipStream_t)stream, ln_g, ln_b, ln_eps);
+}
+
+extern "C" int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
+                                      const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
+                                      int max_groups, void* ws_dev, size_t ws_bytes, void* stream) {
+  return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, ws_dev, ws_bytes,
+                         stream, nullptr, nullptr, 0.f);
+}
+
+extern "C" int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
+                                           const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
+                                           int max_groups, const float* ln_gamma_dev, const float* ln_beta_dev,
+                                           float ln_eps, void* ws_dev, size_t ws_bytes, void* stream) {
+  FTN_CHECK_ARG(ln_gamma_dev && ln_beta_dev && ln_eps >= 0.f, "ftn_timesblock_forward_norm: LayerNorm parameters");
+  return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, ws_dev, ws_bytes,
+                         stream, ln_gamma_dev, ln_beta_dev, ln_eps);
+}
+
+extern "C" int ftn_residual_layernorm(const float* x_dev, const float* new_dev, float* out_dev, long long rows, int C,
+                                      const float* ln_gamma_dev, const float* ln_beta_dev, float ln_eps,
+                                      void* stream) {
+  FTN_CHECK_ARG(x_dev && new_dev && out_dev && ln_gamma_dev && ln_beta_dev, "ftn_residual_layernorm: null pointer");
+  FTN_CHECK_ARG(rows >= 1 && rows <= 0x7fffffffLL * 4 && C >= 1, "ftn_residual_layernorm: rows=%lld C=%d", rows, C);
+  hipLaunchKernelGGL(k_resid_ln, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x_dev, new_dev,
+                     out_dev, ln_gamma_dev, ln_beta_dev, ln_eps, rows, C);
+  FTN_CHECK_LAUNCH();
+  return 0;
 }

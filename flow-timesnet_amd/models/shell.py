@@ -509,7 +509,12 @@ class TimesNet(nn.Module):
         for blk in self.blocks:
             object.__setattr__(blk, "period_selector", self.period_selector)
         recompute = self.use_checkpoint and torch.is_grad_enabled()
+        fuse_norm = not recompute and not (self.training and self.dropout > 0.0)
         for blk in self.blocks:
+            if fuse_norm:
+                # eval: dropout is the identity, so residual + shared LayerNorm ride in the block's last kernel
+                seq = blk(seq, post_norm=self.layer_norm)
+                continue
             new = checkpoint(blk, seq, use_reentrant=False) if recompute else blk(seq)
             seq = _norm(self.layer_norm, seq + self.residual_dropout(new - seq))
 

@@ -344,7 +344,10 @@ class TimesBlock(nn.Module):
         return self._pack
 
     # ---- forward ---------------------------------------------------------------
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, post_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+        """``post_norm`` (extension, used by the TimesNet shell in eval mode): also apply the model's
+        per-block ``post_norm(x + (block(x) - x))`` (reference :2050-2058) - inside the last HIP kernel
+        on the HIP backend, as plain torch ops otherwise."""
         if x.ndim != 3:
             raise ValueError("TimesBlock expects input shaped [B, L, d_model]")
         if self.period_selector is None:
@@ -361,16 +364,34 @@ class TimesBlock(nn.Module):
 
         use_hip = (_hip_eligible(x) and self._standard_inception()
                    and not (self.training and self._dropout > 0.0))
+        fused = post_norm is not None and use_hip and _affine_layernorm(post_norm, x.size(-1))
         if not use_hip:
             self._last_backend = "torch"
-            return self._forward_torch(x)
-        self._last_backend = "hip"
-        self._hip_calls += 1
-        return self._forward_hip(x)
+            new = self._forward_torch(x)
+        else:
+            self._last_backend = "hip"
+            self._hip_calls += 1
+            new = self._forward_hip(x, post_norm if fused else None)
+        if post_norm is not None and not fused:
+            new = _layer_norm_fp32(post_norm, x + (new - x))
+        return new
 
     # ---- HIP backend -----------------------------------------------------------
-    def _forward_hip(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward_hip(self, x: torch.Tensor, post_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
         from .. import lib, runtime
+
+        norm = None
+        if post_norm is not None:
+            norm = (post_norm.weight.detach().float().contiguous(), post_norm.bias.detach().float().contiguous(),
+                    post_norm.eps)
+
+        def unchanged():
+            # the reference returns x itself (:796-797); the shell then normalises x + (x - x)
+            if norm is None:
+                return x
+            xc = x.detach().float().contiguous()
+            y = runtime.residual_layernorm(xc, xc, *norm)
+            return y if y.dtype == x.dtype else y.to(x.dtype)
 
         B, L, _ = x.shape
         sel_mod = self.period_selector
@@ -384,14 +405,14 @@ class TimesBlock(nn.Module):
             sel = sel_mod.select_device(xf)
             if sel is None:                                            # reference :796-797
                 self._last_raw_period_count = self._last_valid_period_count = self._last_group_count = 0
-                return x
+                return unchanged()
             self._lazy_sel = sel                                       # counters resolve on access
         else:
             # foreign selector (reference tests inject stubs, :711-713) or env-flag
             # grouping: group on the host, upload descriptor + weights
             periods, amps = sel_mod(x)
             if periods.numel() == 0:
-                return x
+                return unchanged()
             if periods.numel() > FTN_KMAX:
                 raise ValueError(f"{periods.numel()} period candidates exceed FTN_KMAX={FTN_KMAX}")
             grp = PeriodGrouper(periods.detach().to("cpu", torch.long), amps.detach().float().cpu(), seq_len=L,
@@ -403,14 +424,14 @@ class TimesBlock(nn.Module):
             self._last_valid_period_count = int(grp.valid_mask.sum().item())
             self._last_group_count = int(grp.periods.numel())
             if grp.periods.numel() == 0:
-                return x
+                return unchanged()
             w = _group_weights(amps.detach().float().cpu(), grp.mapping, grp.periods.numel(), B)
             dh = lib.desc_from_periods(grp.periods.tolist(), L, 1, 2 ** 30)
             if int(dh.n_groups) != grp.periods.numel():
                 raise RuntimeError("host grouping and descriptor disagree")
             sel = runtime.selection_from_host(dh, w, x.device)
         wblob, plan = self._packed(x.device)
-        y = runtime.timesblock_forward(xf, plan, wblob, sel)
+        y = runtime.timesblock_forward(xf, plan, wblob, sel, norm)
         if _env_on("TIMESBLOCK_VEC_DISABLE"):
             # same kernels either way (the two reference paths are the same math, :866-953);
             # only the counters differ.  Reading the group count synchronises, as the reference does.
@@ -458,6 +479,21 @@ class TimesBlock(nn.Module):
             term = delta * w[:, g].to(x.dtype).view(B, 1, 1)
             combined = term if combined is None else combined + term
         return x + combined
+
+
+def _affine_layernorm(m, C: int) -> bool:
+    return (isinstance(m, nn.LayerNorm) and tuple(m.normalized_shape) == (C,) and m.weight is not None
+            and m.bias is not None)
+
+
+def _layer_norm_fp32(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """LayerNorm with fp32 statistics and fp32 parameters for half inputs (reference :30-34)."""
+    if isinstance(module, nn.LayerNorm):
+        cd = torch.float32 if x.dtype in (torch.float16, torch.bfloat16) else x.dtype
+        w = None if module.weight is None else module.weight.to(cd)
+        b = None if module.bias is None else module.bias.to(cd)
+        return F.layer_norm(x.to(cd), module.normalized_shape, weight=w, bias=b, eps=module.eps).to(x.dtype)
+    return module(x)
 
 
 def _group_weights(amps: torch.Tensor, mapping: torch.Tensor, G: int, B: int) -> torch.Tensor:

@@ -135,7 +135,10 @@ def selection_from_host(desc_host: FtnDesc, weights: torch.Tensor, device: torch
 
 
 # ------------------------------------------------------------------ conv path
-def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel: Selection) -> torch.Tensor:
+def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel: Selection,
+                       norm=None) -> torch.Tensor:
+    """``norm=(gamma, beta, eps)`` appends the model's per-block ``LayerNorm(x + (y - x))``
+    (reference :2050-2058) to the same call."""
     lib = _lib.load()
     B, L, _ = x.shape
     st = state(x.device)
@@ -144,10 +147,28 @@ def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel:
         raise ValueError("ftn_timesblock_workspace_bytes rejected the shape")
     ws = st.get_workspace(need)
     y = torch.empty_like(x)
+    if norm is not None:
+        g, b, eps = norm
+        check(lib.ftn_timesblock_forward_norm(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
+                                              _ptr(sel.weights), sel.max_groups, _ptr(g), _ptr(b), float(eps),
+                                              _ptr(ws), ws.numel(), _stream(x.device)),
+              "ftn_timesblock_forward_norm")
+        return y
     check(lib.ftn_timesblock_forward(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
                                      _ptr(sel.weights), sel.max_groups, _ptr(ws), ws.numel(),
                                      _stream(x.device)), "ftn_timesblock_forward")
     return y
+
+
+def residual_layernorm(x: torch.Tensor, new: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                       eps: float) -> torch.Tensor:
+    """LayerNorm over the last axis of ``x + (new - x)`` (fp32, contiguous)."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib.ftn_residual_layernorm(_ptr(x), _ptr(new), _ptr(out), x.numel() // Cc, Cc, _ptr(gamma), _ptr(beta),
+                                     float(eps), _stream(x.device)), "ftn_residual_layernorm")
+    return out
 
 
 # ------------------------------------------------------------------ LRTC

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTN_ABI_VERSION 4
+#define FTN_ABI_VERSION 5
 #define FTN_KMAX 16      /* max period candidates / groups per block call        */
 #define FTN_MAXBR 8      /* max kernels in kernel_set                             */
 
@@ -129,6 +129,17 @@ size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max
 int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
                            int max_groups, void* ws_dev, size_t ws_bytes, void* stream);
+/* The same call followed by the caller's per-block epilogue of TimesNet.forward (:2050-2058, eval mode):
+ *   y = LayerNorm_C( x + (block(x) - x) ; gamma, beta, eps )
+ * fused into the last kernel when d_model <= 64 (bottleneck mode), one extra in-place row pass otherwise. */
+int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
+                                const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
+                                int max_groups, const float* ln_gamma_dev, const float* ln_beta_dev, float ln_eps,
+                                void* ws_dev, size_t ws_bytes, void* stream);
+/* out[row][:] = LayerNorm_C( x[row][:] + (new[row][:] - x[row][:]) ) for rows x C fp32 matrices (in place
+ * allowed: out == new).  Used when a block returns x unchanged (no valid period, :796-797). */
+int ftn_residual_layernorm(const float* x_dev, const float* new_dev, float* out_dev, long long rows, int C,
+                           const float* ln_gamma_dev, const float* ln_beta_dev, float ln_eps, void* stream);
 
 /* ---- LowRankTemporalContext (:1340-1371) -------------------------------------- */
 /* basis buffer: (L+1)*R floats = basis[l][r] (DCT-II columns r=1..R, centred over l,

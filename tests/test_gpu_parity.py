@@ -313,3 +313,50 @@ def test_lazy_build_under_inference_mode(ftn, dev):
     P = {k: v.detach().cpu() for k, v in blk.inception.state_dict().items()}
     ref, _ = orc.timesblock_forward(x.cpu(), P, [(3, 3), (5, 5)], "gelu", 3, 48, 1)
     np.testing.assert_allclose(y1.cpu().numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
+# ---- per-block residual + shared LayerNorm epilogue (reference TimesNet.forward :2050-2058) ----
+@pytest.mark.parametrize("hyper,C,L", [("pipeline", 64, 96), ("pipeline", 24, 50), ("pipeline", 128, 48),
+                                       ("minimal", 16, 96), ("rect", 32, 60)])
+@pytest.mark.parametrize("engine", ENGINES)
+def test_post_norm_epilogue(hyper, C, L, engine, ftn, dev):
+    """block(x, post_norm=ln) == LayerNorm(x + (block(x) - x)): fused into k_out for d_model <= 64 in
+    bottleneck mode, the in-place row kernel otherwise; checked against torch ops on the HIP block's own
+    output and against the CPU oracle end to end."""
+    case = dict(hyper=hyper, C=C, seed=11)
+    blk, P, ks, act = _block(ftn, case, dev, engine)
+    blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(3, L)
+    ln = torch.nn.LayerNorm(C).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(torch.linspace(0.5, 1.5, C))
+        ln.bias.copy_(torch.linspace(-0.2, 0.3, C))
+    x = torch.from_numpy(ftn.synth.make_input(5, L, C, seed=4, planted=(12, 8, 6))).to(dev)
+    with torch.inference_mode():
+        y = blk(x)
+        z = blk(x, post_norm=ln)
+        want = torch.nn.functional.layer_norm(x + (y - x), (C,), ln.weight, ln.bias, ln.eps)
+    assert blk._last_backend == "hip"
+    np.testing.assert_allclose(z.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6)
+    ref, _ = orc.timesblock_forward(x.cpu(), P, ks, act, 3, L, 1)
+    xc = x.cpu()
+    with torch.no_grad():
+        want_o = torch.nn.functional.layer_norm(xc + (ref - xc), (C,), ln.weight.cpu(), ln.bias.cpu(), ln.eps)
+    np.testing.assert_allclose(z.cpu().numpy(), want_o.numpy(), rtol=RTOL, atol=5e-5)
+
+
+def test_post_norm_when_block_is_identity(ftn, dev):
+    """No valid period -> the block returns x (:796-797) and the shell normalises x + (x - x)."""
+    case = dict(hyper="pipeline", C=16, seed=2)
+    blk, P, ks, act = _block(ftn, case, dev)
+
+    class Stub(torch.nn.Module):
+        def forward(self, x):
+            return torch.tensor([0, -3], device=x.device), torch.ones(x.size(0), 2, device=x.device)
+
+    blk.period_selector = Stub()
+    ln = torch.nn.LayerNorm(16).to(dev)
+    x = torch.randn(3, 40, 16, device=dev)
+    with torch.inference_mode():
+        z = blk(x, post_norm=ln)
+        want = ln(x)
+    np.testing.assert_allclose(z.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6)

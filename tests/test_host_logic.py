@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(ftn):
     assert declared == set(ftn.lib.EXPORTS), declared ^ set(ftn.lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ftn_abi_version() == 4
+    assert lib.ftn_abi_version() == ftn.lib.ABI_VERSION == 5
 
 
 def test_struct_sizes_match_header(ftn):
