@@ -256,6 +256,7 @@ class TimesNet(nn.Module):
         if self.context_rank < 0:
             raise ValueError("context_rank must be non-negative")
         self.context_scale_default = float(context_scale)
+        self._last_head_backend = "torch"
 
     # ---- lazy construction ------------------------------------------------------
     def _lazy(self, name: str, ref: torch.Tensor, ok: Callable[[nn.Module], bool],
@@ -425,6 +426,42 @@ class TimesNet(nn.Module):
             return msv.to(device=ref.device, dtype=ref.dtype).expand_as(ref).clone()
         return ref.new_full(ref.shape, self.min_sigma)
 
+    # ---- HIP heads (ftn_head_forward) ----------------------------------------------
+    def _hip_heads_ok(self, seq: torch.Tensor, window: torch.Tensor) -> bool:
+        params = (self.forecast_time_proj.weight, self.mu_head.weight, self.sigma_head.weight)
+        return (seq.is_cuda and seq.dtype == torch.float32 and window.dtype == torch.float32
+                and not (torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in params)))
+                and self.d_model % 4 == 0 and self.d_model <= 128
+                and window.stride(2) == 1 and window.stride(1) == window.size(2))
+
+    def _heads_hip(self, seq, window, late, steps: int, hist: int):
+        """Time projection as one batched GEMM straight into [B, steps, d_model] (no permute copies),
+        then mu / sigma heads + history tail + late bias + softplus + floors + the finite-positive
+        check in one kernel (reference :2066-2102)."""
+        from .. import runtime
+
+        B, L, _ = seq.shape
+        wt, bt = self.forecast_time_proj.weight, self.forecast_time_proj.bias
+        if steps != self.pred_len:
+            wt, bt = wt[-steps:], bt[-steps:]
+        hidden = torch.baddbmm(bt.detach().view(1, -1, 1), wt.detach().unsqueeze(0).expand(B, -1, -1), seq.detach())
+        msv = self.min_sigma_vector
+        floor_vec = None
+        if isinstance(msv, torch.Tensor) and msv.numel() > 0:
+            floor_vec = msv.to(device=seq.device, dtype=torch.float32).reshape(-1).contiguous()
+        late_c = None if late is None else late.detach().float().contiguous()
+        rate, dispersion, bad = runtime.head_forward(
+            hidden.contiguous(), self.mu_head.weight.detach(), self.mu_head.bias.detach(),
+            self.sigma_head.weight.detach(), self.sigma_head.bias.detach(), window[:, -hist:, :], hist, late_c,
+            floor_vec, self.min_sigma)
+        self._last_head_backend = "hip"
+        flag = int(bad.item())
+        if flag & 1:
+            raise RuntimeError("Predicted rate must be finite and strictly positive")
+        if flag & 2:
+            raise RuntimeError("Predicted dispersion must be finite and strictly positive")
+        return rate, dispersion
+
     # ---- forward ------------------------------------------------------------------
     def forward(self, x: torch.Tensor, x_mark: Optional[torch.Tensor] = None,
                 series_static: Optional[torch.Tensor] = None,
@@ -445,11 +482,16 @@ class TimesNet(nn.Module):
         L = window.size(1)
         feats_in = window
 
-        # -- per-series context vector [B, N, ctx]
+        # -- per-series context vector [Bc, N, ctx].  Every op on it is row-wise, so when the static
+        #    features / ids are shared by the batch (2-D / 1-D inputs, the pipeline's case) it is built
+        #    once (Bc = 1) and broadcast; the reference expands to B first (:1883-1956), same values.
+        shared = ((series_static is None or series_static.ndim == 2)
+                  and (series_ids is None or series_ids.ndim == 1 or series_ids.size(0) == 1))
+        Bc = 1 if shared else B
         parts = []
         if self.static_proj is not None and series_static is not None:
             if series_static.ndim == 2:
-                st = series_static.unsqueeze(0).expand(B, -1, -1)
+                st = series_static.unsqueeze(0).expand(Bc, -1, -1)
             elif series_static.ndim == 3:
                 if series_static.size(0) != B:
                     raise ValueError("series_static batch dimension must match input batch size")
@@ -470,10 +512,10 @@ class TimesNet(nn.Module):
                 ids = series_ids.unsqueeze(0) if series_ids.ndim == 1 else series_ids
                 if ids.ndim != 2:
                     raise ValueError("series_ids must have shape [N] or [B, N]")
-            if ids.size(0) == 1 and B > 1:
-                ids = ids.expand(B, -1)
+            if ids.size(0) == 1 and Bc > 1:
+                ids = ids.expand(Bc, -1)
             if series_ids is not None:
-                if ids.size(0) != B:
+                if ids.size(0) not in (1, B):
                     raise ValueError("series_ids batch dimension does not match input")
                 if ids.size(1) != N:
                     raise ValueError("series_ids length must match number of series")
@@ -489,7 +531,7 @@ class TimesNet(nn.Module):
             if self.use_zero_mean_context and self.context_coeff is not None and self.temporal_context is not None:
                 coeff = self.context_coeff(ctx.to(self.context_coeff.weight.dtype))
                 signal = self.temporal_context(coeff, L)              # HIP LRTC kernel on ROCm tensors
-                if signal.ndim != 3 or signal.shape != feats_in.shape:
+                if signal.ndim != 3 or signal.shape != (Bc,) + tuple(feats_in.shape[1:]):
                     raise RuntimeError("Temporal context must align with the [B, L, N] input")
                 feats_in = feats_in + signal.to(feats_in.dtype)
             if self.use_constant_context_bias and self.context_proj is not None:
@@ -518,17 +560,24 @@ class TimesNet(nn.Module):
             new = checkpoint(blk, seq, use_reentrant=False) if recompute else blk(seq)
             seq = _norm(self.layer_norm, seq + self.residual_dropout(new - seq))
 
+        late = None
+        if (ctx is not None and self.late_bias_head is not None and self.late_bias_norm is not None
+                and isinstance(self.late_bias_gate, nn.Parameter)):
+            c = ctx.to(dtype=self.late_bias_head.weight.dtype, device=self.late_bias_head.weight.device)
+            lb = self.late_bias_head(_norm(self.late_bias_norm, c)).permute(0, 2, 1)      # [Bc, steps, N]
+            late = self.late_bias_gate.to(dtype=lb.dtype, device=lb.device) * lb
+
+        if self._hip_heads_ok(seq, window):
+            return self._heads_hip(seq, window, late, steps, hist)
+
         # -- time projection L -> pred_len on [B, d_model, L], heads back on [B, steps, d_model]
         proj = self.forecast_time_proj(seq.permute(0, 2, 1).contiguous())
         if steps != self.pred_len:
             proj = proj[:, :, -steps:]
         hidden = proj.permute(0, 2, 1).contiguous()
         pre = self.mu_head(hidden) + tail.to(window.dtype)
-        if (ctx is not None and self.late_bias_head is not None and self.late_bias_norm is not None
-                and isinstance(self.late_bias_gate, nn.Parameter)):
-            c = ctx.to(dtype=self.late_bias_head.weight.dtype, device=self.late_bias_head.weight.device)
-            lb = self.late_bias_head(_norm(self.late_bias_norm, c)).permute(0, 2, 1).contiguous()
-            pre = pre + self.late_bias_gate.to(dtype=pre.dtype, device=pre.device) * lb.to(pre.dtype)
+        if late is not None:
+            pre = pre + late.to(pre.dtype)
         rate = F.softplus(pre.float(), beta=1.0, threshold=20).to(pre.dtype) + 1e-6
         sig = self.sigma_head(hidden)
         sig = F.softplus(sig.float(), beta=1.0, threshold=20).to(sig.dtype)

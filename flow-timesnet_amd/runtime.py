@@ -171,6 +171,34 @@ def residual_layernorm(x: torch.Tensor, new: torch.Tensor, gamma: torch.Tensor, 
     return out
 
 
+# ------------------------------------------------------------------ model shell
+def head_forward(hidden: torch.Tensor, w_mu: torch.Tensor, b_mu: torch.Tensor, w_sigma: torch.Tensor,
+                 b_sigma: torch.Tensor, tail: torch.Tensor, hist: int, late, floor_vec, floor_scalar: float):
+    """Fused rate / dispersion heads.  ``hidden`` [B,S,D] contiguous fp32; ``tail`` a (possibly strided
+    along the batch) view [B,hist,N] of the input window; ``late`` None or contiguous [1|B,S,N].
+    Returns ``(rate, dispersion, bad_flag)``; ``bad_flag`` is a 1-element int32 device tensor."""
+    lib = _lib.load()
+    B, S, D = hidden.shape
+    N = w_mu.shape[0]
+    if tail.stride(2) != 1 or tail.stride(1) != N or tail.shape != (B, hist, N):
+        raise ValueError("tail must be a [B, hist, N] view with contiguous rows")
+    dev = hidden.device
+    rate = torch.empty(B, S, N, dtype=torch.float32, device=dev)
+    disp = torch.empty(B, S, N, dtype=torch.float32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    late_bs = 0
+    if late is not None:
+        if late.shape[-2:] != (S, N) or not late.is_contiguous():
+            raise ValueError("late bias must be contiguous [1|B, S, N]")
+        late_bs = S * N if late.shape[0] == B and B > 1 else 0
+    check(lib.ftn_head_forward(_ptr(hidden), B * S, S, D, N, _ptr(w_mu), _ptr(b_mu), _ptr(w_sigma), _ptr(b_sigma),
+                               _ptr(tail), tail.stride(0) if B > 1 else 0, int(hist),
+                               _ptr(late) if late is not None else None, late_bs,
+                               _ptr(floor_vec) if floor_vec is not None else None, float(floor_scalar),
+                               _ptr(rate), _ptr(disp), _ptr(bad), _stream(dev)), "ftn_head_forward")
+    return rate, disp, bad
+
+
 # ------------------------------------------------------------------ LRTC
 def lrtc_forward(coeff: torch.Tensor, L: int, scale: torch.Tensor, x: torch.Tensor | None) -> torch.Tensor:
     lib = _lib.load()

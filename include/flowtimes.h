@@ -152,6 +152,23 @@ int ftn_lrtc_forward(const float* coeff_dev, const float* basis_dev, const float
                      const float* x_dev_or_null, float* out_dev, int B, int L, int N, int R,
                      void* stream);
 
+/* ---- model shell around the block stack (TimesNet.forward) ------------------------ */
+/* Rate / dispersion heads (:2066-2102), one pass over hidden[rows = B*S][D] (the output of
+ * forecast_time_proj, time-major):
+ *   pre        = hidden W_mu^T + b_mu + tail[b, min(s, hist-1), :] (+ late[b, s, :])
+ *   rate       = softplus(pre) + 1e-6
+ *   dispersion = softplus(hidden W_sigma^T + b_sigma) + floor + 1e-6
+ * W_* are nn.Linear weights [N][D]; tail points at x[b=0, T-hist, 0] with batch stride tail_bstride
+ * (elements); late (optional) is gate * late_bias laid out [.., S, N] with batch stride late_bstride
+ * (0 = shared by the batch); floor is min_sigma_vector[N] or the scalar.  *bad_flag_dev gets bit 0 / 1
+ * OR-ed in when a rate / dispersion is not finite and > 0 (the reference raises RuntimeError, :2095-2098);
+ * the caller zeroes it.  D must be a multiple of 4, <= 128. */
+int ftn_head_forward(const float* hidden_dev, long long rows, int S, int D, int N, const float* w_mu_dev,
+                     const float* b_mu_dev, const float* w_sigma_dev, const float* b_sigma_dev,
+                     const float* tail_dev, long long tail_bstride, int hist, const float* late_dev_or_null,
+                     long long late_bstride, const float* floor_vec_dev_or_null, float floor_scalar,
+                     float* rate_dev, float* disp_dev, int* bad_flag_dev, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------- */
 /* hipEvent brackets around the 6 stages (A pw-in, B conv, C fused pointwise chain,
  * D conv, E pw-out, F combine) of every following ftn_timesblock_forward call (up to

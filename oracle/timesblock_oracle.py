@@ -278,3 +278,28 @@ def lrtc_forward(coeff: torch.Tensor, L: int, scale: float) -> torch.Tensor:
     ctx = torch.einsum("lr,bnr->bln", basis, coeff)                     # :1368
     ctx = ctx - ctx.mean(dim=1, keepdim=True)                           # :1369
     return ctx * torch.as_tensor(scale, dtype=coeff.dtype)             # :1370-1371
+
+
+# ---------------------------------------------------------------------------
+# Model shell pieces around the block stack
+# ---------------------------------------------------------------------------
+def block_post_norm(x: torch.Tensor, new: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                    eps: float = 1e-5) -> torch.Tensor:
+    """Per-block epilogue of TimesNet.forward in eval mode (reference models/timesnet.py:2050-2058):
+    ``LayerNorm(seq + dropout(updated - seq))`` with dropout = identity."""
+    return F.layer_norm(x + (new - x), (x.shape[-1],), gamma, beta, eps)
+
+
+def model_heads(hidden: torch.Tensor, w_mu: torch.Tensor, b_mu: torch.Tensor, w_sigma: torch.Tensor,
+                b_sigma: torch.Tensor, tail: torch.Tensor, late: Optional[torch.Tensor] = None,
+                floor=1e-3) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rate / dispersion heads of TimesNet.forward (reference :2066-2102).  ``hidden`` [B,S,D] is the
+    time-projected feature map, ``tail`` [B,S,N] the (edge-padded) last observed values (:2008-2014),
+    ``late`` the gated late bias [1|B,S,N] (:2080-2090), ``floor`` min_sigma or min_sigma_vector."""
+    pre = F.linear(hidden, w_mu, b_mu) + tail
+    if late is not None:
+        pre = pre + late
+    rate = F.softplus(pre.float(), beta=1.0, threshold=20) + 1e-6
+    sig = F.softplus(F.linear(hidden, w_sigma, b_sigma).float(), beta=1.0, threshold=20)
+    floor_t = floor if isinstance(floor, torch.Tensor) else torch.full_like(sig, float(floor))
+    return rate, sig + floor_t + 1e-6

@@ -87,6 +87,8 @@ SHELL_CASES = {
                             dropout=0.0, activation="gelu", mode="direct", use_embedding_norm=False,
                             min_sigma_vector=[0.1, 0.2, 0.3, 0.4], static_proj_dim=None, static_layernorm=False,
                             id_embed_dim=0, use_late_bias_head=False), dict(static=True, n=4)),
+    # per-sample static features / ids: the context is NOT shared by the batch
+    "context_per_sample": (dict(CFG), dict(static=True, ids=True, per_sample=True)),
 }
 
 
@@ -107,6 +109,9 @@ def test_timesnet_shell_mirror_matches_reference(name, ftn):
         kw["series_ids"] = torch.tensor([4, 0, 2, 7, 1][:N])
     if opt.get("marks"):
         kw["x_mark"] = torch.randn(B, L, opt["marks"], generator=g)
+    if opt.get("per_sample"):
+        kw["series_static"] = torch.randn(B, N, 3, generator=g)
+        kw["series_ids"] = torch.stack([torch.tensor([4, 0, 2, 7, 1][:N])] * B)
     with torch.no_grad():
         torch.manual_seed(0)
         want = ref.TimesNet(**cfg).eval()

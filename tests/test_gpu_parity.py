@@ -291,6 +291,7 @@ def test_full_model_matches_reference(name, manifest, golden, ftn, dev):
     with torch.inference_mode():
         rate, disp = model(torch.from_numpy(g["x"]).to(dev), **kw)
     assert all(b._last_backend == "hip" for b in model.blocks)
+    assert model._last_head_backend == "hip"
     if model.temporal_context is not None:
         assert model.temporal_context._last_backend == "hip"
     assert model.period_selector.last_selected_periods.tolist() == g["periods"].tolist()
@@ -360,3 +361,55 @@ def test_post_norm_when_block_is_identity(ftn, dev):
         z = blk(x, post_norm=ln)
         want = ln(x)
     np.testing.assert_allclose(z.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6)
+
+
+# ---- fused rate / dispersion heads (reference TimesNet.forward :2066-2102) ----
+@pytest.mark.parametrize("B,S,D,N,hist,late,floor", [
+    (3, 6, 8, 5, 6, "shared", "scalar"),        # ragged N (scalar loads/stores)
+    (2, 12, 64, 512, 12, "batch", "vector"),    # vector path, 8 series slices
+    (4, 5, 16, 72, 3, None, "scalar"),          # history shorter than the horizon: tail edge-padded
+    (2, 1, 128, 200, 1, "shared", "vector"),    # recursive mode (one step), d_model 128
+    (1, 24, 24, 8, 24, "batch", "scalar"),      # d_model not a multiple of 16
+])
+def test_heads_match_oracle(B, S, D, N, hist, late, floor, ftn, dev):
+    g = torch.Generator().manual_seed(B * 100 + S)
+    T = hist + 5
+    x = 3.0 * torch.randn(B, T, N, generator=g)
+    hidden = torch.randn(B, S, D, generator=g)
+    w_mu, w_sg = 0.3 * torch.randn(N, D, generator=g), 0.3 * torch.randn(N, D, generator=g)
+    b_mu, b_sg = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    hidden[0, 0] *= 30.0                          # drive some pre-activations past the softplus threshold
+    lt = None if late is None else 0.5 * torch.randn(B if late == "batch" else 1, S, N, generator=g)
+    fv = torch.rand(N, generator=g) if floor == "vector" else None
+    tail = x[:, -hist:, :]
+    tail_full = tail if hist == S else torch.cat([tail, tail[:, -1:, :].expand(-1, S - hist, -1)], dim=1)
+    want_r, want_d = orc.model_heads(hidden, w_mu, b_mu, w_sg, b_sg, tail_full, lt,
+                                     fv.view(1, 1, N) if fv is not None else 1e-3)
+    to = lambda t: None if t is None else t.to(dev)
+    xd = x.to(dev)
+    rate, disp, bad = ftn.runtime.head_forward(to(hidden), to(w_mu), to(b_mu), to(w_sg), to(b_sg), xd[:, -hist:, :],
+                                               hist, to(lt), to(fv), 1e-3)
+    assert int(bad.item()) == 0
+    np.testing.assert_allclose(rate.cpu().numpy(), want_r.numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(disp.cpu().numpy(), want_d.numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_heads_flag_bad_outputs(ftn, dev):
+    """A non-finite pre-activation must surface (the reference raises RuntimeError, :2095-2098)."""
+    B, S, D, N = 2, 4, 8, 8
+    hidden = torch.randn(B, S, D, device=dev)
+    w = torch.randn(N, D, device=dev)
+    b = torch.zeros(N, device=dev)
+    x = torch.randn(B, S, N, device=dev)
+    x[1, 2, 3] = float("inf")
+    _, _, bad = ftn.runtime.head_forward(hidden, w, b, w, b, x, S, None, None, 1e-3)
+    assert int(bad.item()) == 1
+    hidden[0, 1, 0] = float("nan")
+    _, _, bad = ftn.runtime.head_forward(hidden, w, b, w, b, x, S, None, None, 1e-3)
+    assert int(bad.item()) == 3
+    model = ftn.models.TimesNet(input_len=16, pred_len=4, d_model=8, n_layers=1, k_periods=2, kernel_set=[(3, 3)],
+                                dropout=0.0, activation="gelu", mode="direct").eval()
+    xin = torch.randn(2, 16, 8, device=dev)
+    xin[0, -1, 0] = float("inf")
+    with torch.inference_mode(), pytest.raises(RuntimeError, match="rate must be finite"):
+        model(xin)
