@@ -286,17 +286,23 @@ def model_bench(pkg, dev, B, L, N, d_model, ks, ratio, K, H=96, layers=3, R=16, 
         for p in model.parameters():
             if float(p.detach().abs().sum()) == 0.0:
                 p.copy_(0.05 * torch.randn(p.shape, generator=g).to(p.device))
-    with torch.inference_mode():
+    def timed(fn):
         for _ in range(2):
-            model(x)
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            model(x)
+            fn()
         e1.record()
         torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    return {"ms": ms, "series_per_s": B * N / (ms * 1e-3), "windows_per_s": B / (ms * 1e-3),
+        return e0.elapsed_time(e1) / iters
+
+    with torch.inference_mode():
+        ms_eager = timed(lambda: model(x))
+    graphed = pkg.graph.GraphedForward(model, x)            # one hipGraphLaunch per forward
+    ms = timed(lambda: graphed(graphed.inputs[0]))          # finite-positive check (1 host read) included
+    return {"ms": ms, "ms_eager_launches": ms_eager, "series_per_s": B * N / (ms * 1e-3),
+            "windows_per_s": B / (ms * 1e-3), "mode": "HIP graph replay + deferred output check",
             "config": f"TimesNet B={B} L={L}->H={H} N={N} d_model={d_model} d_ff={4 * d_model} layers={layers} "
                       f"k={K} context_rank={R} id_embed=32 (reference CPU, 8 vCPU, survey: 3655 ms)"}
 

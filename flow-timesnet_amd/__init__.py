@@ -7,7 +7,9 @@ Sub-modules
 ``lib``              ctypes binding of ``csrc/libflowtimes_hip.so`` (the C-ABI in ``include/flowtimes.h``)
 ``pack``             host-side weight folding/packing for the HIP kernels
 ``models.timesnet``  drop-in mirrors of the reference modules
+``models.shell``     mirror of the TimesNet model shell; HIP embedding / head kernels around the blocks
 ``dist``             batch-sharded multi-GPU forward (RCCL via torch.distributed)
+``graph``            HIP-graph capture / replay of an inference forward
 """
 from . import synth  # noqa: F401
 
@@ -15,6 +17,6 @@ from . import synth  # noqa: F401
 def __getattr__(name):  # lazy: keeps `import flow_timesnet_amd.synth` torch-free
     import importlib
 
-    if name in ("lib", "pack", "models", "dist", "grouping", "runtime"):
+    if name in ("lib", "pack", "models", "dist", "grouping", "runtime", "graph"):
         return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

@@ -34,8 +34,8 @@ struct HeadArgs {
 };
 
 // One workgroup owns a 64-wide slice of the N output series: the two weight slices live in LDS in
-// MFMA A-fragment order (row i of tile o is series n0 + 16*(i>>2) + 4*o + (i&3), so a lane ends up with 16
-// consecutive series of one (b, s) row = one 64-byte run, four lanes = 256 bytes).  Its four waves walk
+// MFMA A-fragment order (row i of tile o is series n0 + 16*o + i: the four q-lanes of a row cover one
+// 64-byte run per load / store instruction).  Its four waves walk
 // 16-row tiles of `hidden`; per tile 2 x 4 x D/4 MFMAs, then the fused epilogue.
 template <int NS, bool VEC>
 __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
     const int S = t % NS;
     t /= NS;
     const int o = t & 3, h = t >> 2, i = ln & 15, q = ln >> 4;
-    const int n = n0 + 16 * (i >> 2) + 4 * o + (i & 3), k = 16 * S + 4 * q;
+    const int n = n0 + 16 * o + i, k = 16 * S + 4 * q;
     f4 v = {0.f, 0.f, 0.f, 0.f};
     if (n < a.N) {
       const float* __restrict__ W = (h ? a.wsg : a.wmu) + (size_t)n * a.D + k;
@@ -57,22 +57,23 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
     }
     wl[f] = v;
   }
+  // per-series constants of the slice: [0] b_mu, [1] b_sigma, [2] dispersion floor
+  float* cst = (float*)(wl + 2 * 4 * NS * 64);
+  if (threadIdx.x < 192) {
+    const int which = threadIdx.x >> 6, n = n0 + (threadIdx.x & 63);
+    const bool in = n < a.N;
+    float v = which == 2 ? a.floor_s : 0.f;
+    if (in) v = which == 0 ? a.bmu[n] : which == 1 ? a.bsg[n] : (a.floorv ? a.floorv[n] : a.floor_s);
+    cst[threadIdx.x] = v;
+  }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-  const int nl0 = n0 + 16 * q;
-  f4 bm[4], bs[4], fl[4];
-#pragma unroll
-  for (int o = 0; o < 4; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nl0 + 4 * o + r;
-      const bool in = n < a.N;
-      bm[o][r] = in ? a.bmu[n] : 0.f;
-      bs[o][r] = in ? a.bsg[n] : 0.f;
-      fl[o][r] = (in && a.floorv) ? a.floorv[n] : a.floor_s;
-    }
+  const int nl0 = n0 + 4 * q;           // lane (j, q) of tile o holds series nl0 + 16*o .. +3 of row j
   int badbits = 0;
   for (long long t = (long long)blockIdx.y * 4 + wave; t * 16 < a.rows; t += (long long)gridDim.y * 4) {
+    // the weight fragments are re-read from LDS for every row tile: hoisted into registers (128 VGPRs at
+    // d_model 64) they leave one wave per SIMD and nothing to hide the hidden/tail loads behind
+    asm volatile("" ::: "memory");
     const long long row = t * 16 + j;
     const bool rok = row < a.rows;
     const long long rr = rok ? row : a.rows - 1;
@@ -91,11 +92,11 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
     for (int o = 0; o < 4; ++o) {
       f4 tv = {0.f, 0.f, 0.f, 0.f};
       if (VEC) {
-        if (nl0 + 4 * o < a.N) tv = *(const f4*)(tp + 4 * o);
+        if (nl0 + 16 * o < a.N) tv = *(const f4*)(tp + 16 * o);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (nl0 + 4 * o + r < a.N) tv[r] = tp[4 * o + r];
+          if (nl0 + 16 * o + r < a.N) tv[r] = tp[16 * o + r];
       }
       ex[o] = tv;
     }
@@ -120,15 +121,17 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      f4 pre = am[o] + bm[o] + ex[o];                       // mu_head(hidden) + history tail (:2079)
+      const f4 bm = *(const f4*)(cst + 16 * o + 4 * q), bs = *(const f4*)(cst + 64 + 16 * o + 4 * q);
+      const f4 fl = *(const f4*)(cst + 128 + 16 * o + 4 * q);
+      f4 pre = am[o] + bm + ex[o];                          // mu_head(hidden) + history tail (:2079)
       if (lp) {
         f4 lv = {0.f, 0.f, 0.f, 0.f};
         if (VEC) {
-          if (nl0 + 4 * o < a.N) lv = *(const f4*)(lp + 4 * o);
+          if (nl0 + 16 * o < a.N) lv = *(const f4*)(lp + 16 * o);
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (nl0 + 4 * o + r < a.N) lv[r] = lp[4 * o + r];
+            if (nl0 + 16 * o + r < a.N) lv[r] = lp[16 * o + r];
         }
         pre = pre + lv;                                      // + gate * late_bias (:2080-2090)
       }
@@ -136,24 +139,24 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         rt[r] = softplus20(pre[r]) + 1e-6f;                  // :2091
-        dp[r] = softplus20(as[o][r] + bs[o][r]) + fl[o][r] + 1e-6f;   // :2092-2094
-        if (rok && nl0 + 4 * o + r < a.N) {
+        dp[r] = softplus20(as[o][r] + bs[r]) + fl[r] + 1e-6f;         // :2092-2094
+        if (rok && nl0 + 16 * o + r < a.N) {
           if (!(rt[r] > 0.f && rt[r] <= 3.4028234664e38f)) badbits |= 1;
           if (!(dp[r] > 0.f && dp[r] <= 3.4028234664e38f)) badbits |= 2;
         }
       }
       if (!rok) continue;
-      float* __restrict__ rp = a.rate + rr * a.N + nl0 + 4 * o;
-      float* __restrict__ dq = a.disp + rr * a.N + nl0 + 4 * o;
+      float* __restrict__ rp = a.rate + rr * a.N + nl0 + 16 * o;
+      float* __restrict__ dq = a.disp + rr * a.N + nl0 + 16 * o;
       if (VEC) {
-        if (nl0 + 4 * o < a.N) {
+        if (nl0 + 16 * o < a.N) {
           __builtin_nontemporal_store(rt, (f4*)rp);
           __builtin_nontemporal_store(dp, (f4*)dq);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (nl0 + 4 * o + r < a.N) { rp[r] = rt[r]; dq[r] = dp[r]; }
+          if (nl0 + 16 * o + r < a.N) { rp[r] = rt[r]; dq[r] = dp[r]; }
       }
     }
   }
@@ -167,7 +170,7 @@ static int launch_head(const HeadArgs& a, bool vec, hipStream_t st) {
   long long gy = (rtiles + 3) / 4;
   const long long want = (4 * 256 + ntile - 1) / ntile;       // ~4 workgroups per CU in flight
   if (gy > want) gy = want;
-  const size_t lds = (size_t)2 * 4 * NS * 64 * sizeof(f4);
+  const size_t lds = (size_t)2 * 4 * NS * 64 * sizeof(f4) + 192 * sizeof(float);
   if (vec) hipLaunchKernelGGL((k_head<NS, true>), dim3(ntile, (unsigned)gy), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((k_head<NS, false>), dim3(ntile, (unsigned)gy), dim3(256), lds, st, a);
   FTN_CHECK_LAUNCH();
@@ -200,4 +203,208 @@ extern "C" int ftn_head_forward(const float* hidden_dev, long long rows, int S, 
   if (D <= 32) return launch_head<2>(a, vec, st);
   if (D <= 64) return launch_head<4>(a, vec, st);
   return launch_head<8>(a, vec, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Value embedding: out[b][l][:] = x[b][l][:] W^T + add[b?][l][:]   (+ optional LayerNorm over d_model)
+// ---------------------------------------------------------------------------------------------
+// x is the [B, L, N] input window (rows contiguous, batch stride given), W the nn.Linear weight
+// [D][N].  Everything else the reference adds before / after this GEMM is linear in the row and is
+// handed over pre-assembled in `add` ([L][D] shared by the batch, or [B][L][D]): the bias, the
+// positional / time-feature term (gate * LayerNorm(aux) in "decoupled" mode), and the low-rank
+// temporal context and constant context bias pushed through W (so the [B, L, N] context tensor is
+// never materialised).  Reads x once: HBM-bound at 4*B*L*N bytes.
+struct EmbedArgs {
+  const float* x;
+  const float* W;        // [D][N]
+  const float* add;      // optional
+  const float* ln_g;     // optional LayerNorm epilogue ("layer" mode)
+  const float* ln_b;
+  float* out;            // [B][L][D]
+  long long x_bs, add_bs;
+  int B, L, N, D;
+  float ln_eps;
+};
+
+// Workgroup = 4 waves x RT 16-row tiles; the K (= series) axis is walked in 64-wide chunks whose
+// weight slice sits in LDS in A-fragment order, double buffered through registers.  Lane (j, q) ends
+// up with columns 16*o + 4*q .. +3 of row j: 64-byte runs per store instruction, and the LayerNorm
+// reduction is in-lane plus two xor-shuffles.
+template <int NO, bool VEC>
+__global__ __launch_bounds__(256) void k_embed_in(EmbedArgs a) {
+  constexpr int RT = 2, KC = 64, NFR = NO * 4 * 64;            // f4 fragments per chunk
+  constexpr int PER_T = (NFR + 255) / 256;
+  __shared__ f4 wl[2][NFR];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const long long M = (long long)a.B * a.L;
+  const long long row0 = ((long long)blockIdx.x * 4 + wave) * (16 * RT);
+  long long rr[RT];
+  const float* xp[RT];
+  bool rok[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const long long row = row0 + 16 * t + j;
+    rok[t] = row < M;
+    rr[t] = rok[t] ? row : M - 1;
+    const long long b = rr[t] / a.L;
+    xp[t] = a.x + b * a.x_bs + (rr[t] - b * a.L) * a.N;
+  }
+  auto load_w = [&](int kc, f4 (&st)[PER_T]) {
+#pragma unroll
+    for (int p = 0; p < PER_T; ++p) {
+      const int f = threadIdx.x + 256 * p;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (f < NFR) {
+        const int ln = f & 63, S = (f >> 6) & 3, o = f >> 8, i = ln & 15, qq = ln >> 4;
+        const int col = 16 * o + i, k = kc + 16 * S + 4 * qq;
+        if (col < a.D) {
+          const float* __restrict__ wp = a.W + (size_t)col * a.N + k;
+          if (VEC) {
+            if (k < a.N) v = *(const f4*)wp;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (k + e < a.N) v[e] = wp[e];
+          }
+        }
+      }
+      st[p] = v;
+    }
+  };
+  auto store_w = [&](int buf, const f4 (&st)[PER_T]) {
+#pragma unroll
+    for (int p = 0; p < PER_T; ++p) {
+      const int f = threadIdx.x + 256 * p;
+      if (f < NFR) wl[buf][f] = st[p];
+    }
+  };
+  auto load_x = [&](int kc, f4 (&xv)[RT][4]) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int S = 0; S < 4; ++S) {
+        const int k = kc + 16 * S + 4 * q;
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (VEC) {
+          if (k < a.N) v = *(const f4*)(xp[t] + k);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < a.N) v[e] = xp[t][k + e];
+        }
+        xv[t][S] = v;
+      }
+  };
+  f4 acc[RT][NO];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int o = 0; o < NO; ++o) acc[t][o] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 stg[PER_T], xc[RT][4], xn[RT][4];
+  const int nch = (a.N + KC - 1) / KC;
+  load_w(0, stg);
+  load_x(0, xc);
+  store_w(0, stg);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const int buf = c & 1;
+    const bool more = c + 1 < nch;
+    if (more) {
+      load_w((c + 1) * KC, stg);
+      load_x((c + 1) * KC, xn);
+    }
+#pragma unroll
+    for (int S = 0; S < 4; ++S) {
+      f4 wf[NO];
+#pragma unroll
+      for (int o = 0; o < NO; ++o) wf[o] = wl[buf][(o * 4 + S) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+          for (int t = 0; t < RT; ++t) acc[t][o] = mfma16(wf[o][e], xc[t][S][e], acc[t][o]);
+    }
+    if (more) {
+      store_w(buf ^ 1, stg);
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int S = 0; S < 4; ++S) xc[t][S] = xn[t][S];
+    }
+    __syncthreads();
+  }
+  // epilogue: + add, optional LayerNorm, store.  Lane (j = row, q) holds columns cb(o) .. cb(o)+3
+  const float invD = 1.0f / (float)a.D;
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const long long b = rr[t] / a.L;
+    const float* __restrict__ ap = a.add ? a.add + b * a.add_bs + (rr[t] - b * a.L) * a.D : nullptr;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const int cb = 16 * o + 4 * q;
+      if (ap && cb < a.D) acc[t][o] = acc[t][o] + *(const f4*)(ap + cb);      // D % 4 == 0
+    }
+    if (a.ln_g) {
+      float s = 0.f;
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+        if (16 * o + 4 * q < a.D) s += (acc[t][o][0] + acc[t][o][1]) + (acc[t][o][2] + acc[t][o][3]);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mean = s * invD;
+      float ss = 0.f;
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+        if (16 * o + 4 * q < a.D) {
+          const f4 dv = acc[t][o] - mean;
+          ss += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+        }
+      ss += __shfl_xor(ss, 16);
+      ss += __shfl_xor(ss, 32);
+      const float rstd = 1.0f / sqrtf(ss * invD + a.ln_eps);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) {
+        const int cb = 16 * o + 4 * q;
+        if (cb < a.D) acc[t][o] = (acc[t][o] - mean) * rstd * *(const f4*)(a.ln_g + cb) + *(const f4*)(a.ln_b + cb);
+      }
+    }
+    if (!rok[t]) continue;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const int cb = 16 * o + 4 * q;
+      if (cb < a.D) *(f4*)(a.out + rr[t] * a.D + cb) = acc[t][o];
+    }
+  }
+}
+
+template <int NO>
+static int launch_embed(const EmbedArgs& a, bool vec, hipStream_t st) {
+  const long long M = (long long)a.B * a.L;
+  const unsigned nblk = (unsigned)((M + 127) / 128);
+  if (vec) hipLaunchKernelGGL((k_embed_in<NO, true>), dim3(nblk), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_embed_in<NO, false>), dim3(nblk), dim3(256), 0, st, a);
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ftn_embed_forward(const float* x_dev, long long x_bstride, int B, int L, int N, const float* w_dev,
+                                 int D, const float* add_dev_or_null, long long add_bstride,
+                                 const float* ln_gamma_dev_or_null, const float* ln_beta_dev_or_null, float ln_eps,
+                                 float* out_dev, void* stream) {
+  FTN_CHECK_ARG(x_dev && w_dev && out_dev, "ftn_embed_forward: null pointer");
+  FTN_CHECK_ARG(B >= 1 && L >= 1 && N >= 1, "ftn_embed_forward: bad shape B=%d L=%d N=%d", B, L, N);
+  FTN_CHECK_ARG(D >= 4 && D % 4 == 0 && D <= 128, "ftn_embed_forward: d_model=%d must be a multiple of 4, <= 128", D);
+  FTN_CHECK_ARG((ln_gamma_dev_or_null == nullptr) == (ln_beta_dev_or_null == nullptr),
+                "ftn_embed_forward: LayerNorm needs both gamma and beta");
+  FTN_CHECK_ARG((((uintptr_t)out_dev | (uintptr_t)add_dev_or_null | (uintptr_t)ln_gamma_dev_or_null |
+                  (uintptr_t)ln_beta_dev_or_null) & 15) == 0 && add_bstride % 4 == 0,
+                "ftn_embed_forward: out / add / LayerNorm parameters must be 16-byte aligned");
+  EmbedArgs a;
+  a.x = x_dev; a.W = w_dev; a.add = add_dev_or_null; a.ln_g = ln_gamma_dev_or_null; a.ln_b = ln_beta_dev_or_null;
+  a.out = out_dev; a.x_bs = x_bstride; a.add_bs = add_bstride; a.B = B; a.L = L; a.N = N; a.D = D; a.ln_eps = ln_eps;
+  const bool vec = N % 4 == 0 && x_bstride % 4 == 0 && (((uintptr_t)x_dev | (uintptr_t)w_dev) & 15) == 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (D <= 64) return launch_embed<4>(a, vec, st);
+  return launch_embed<8>(a, vec, st);
 }

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "ftn_residual_layernorm": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int, _P, _P, C.c_float, _P]),
     "ftn_head_forward": (C.c_int, [_P, C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_longlong,
                                    C.c_int, _P, C.c_longlong, _P, C.c_float, _P, _P, _P, _P]),
+    "ftn_embed_forward": (C.c_int, [_P, C.c_longlong, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_longlong,
+                                    _P, _P, C.c_float, _P, _P]),
     "ftn_lrtc_basis_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "ftn_lrtc_basis": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "ftn_lrtc_forward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -51,11 +51,15 @@ class PositionalEmbedding(nn.Module):
     def __init__(self, d_model: int) -> None:
         super().__init__()
         self.d_model = int(d_model)
+        self._table = None                     # (key, [L, d_model] fp32): pure function of (L, device)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.ndim != 3:
             raise ValueError("PositionalEmbedding expects input shaped [B, L, C]")
         B, L, _ = x.shape
+        key = (L, str(x.device))
+        if self._table is not None and self._table[0] == key and not torch.is_grad_enabled():
+            return self._table[1].to(x.dtype).unsqueeze(0).expand(B, -1, -1)
         pos = torch.arange(L, device=x.device, dtype=torch.float32).unsqueeze(1)
         freq = torch.exp(torch.arange(0, self.d_model, 2, device=x.device, dtype=torch.float32)
                          * (-math.log(10000.0) / self.d_model))
@@ -63,6 +67,7 @@ class PositionalEmbedding(nn.Module):
         pe[:, 0::2] = torch.sin(pos * freq)
         n_odd = pe[:, 1::2].shape[1]
         pe[:, 1::2] = torch.cos(pos * freq[:n_odd])
+        self._table = (key, pe)
         return pe.to(x.dtype).unsqueeze(0).expand(B, -1, -1)
 
 
@@ -257,6 +262,9 @@ class TimesNet(nn.Module):
             raise ValueError("context_rank must be non-negative")
         self.context_scale_default = float(context_scale)
         self._last_head_backend = "torch"
+        self._last_embed_backend = "torch"
+        self._defer_checks = False
+        self._pending_bad = None
 
     # ---- lazy construction ------------------------------------------------------
     def _lazy(self, name: str, ref: torch.Tensor, ok: Callable[[nn.Module], bool],
@@ -335,7 +343,7 @@ class TimesNet(nn.Module):
             else:
                 self.series_embedding = _place(self.series_embedding, x)
                 if ids_ref is not None:
-                    if vocab_of(ids_ref) > int(self.series_embedding.num_embeddings):
+                    if not self._defer_checks and vocab_of(ids_ref) > int(self.series_embedding.num_embeddings):
                         raise ValueError("series_ids vocabulary expanded between calls")
                     self._series_id_reference = ids_ref.to(device=x.device)
                 elif self._series_id_reference is None:
@@ -426,6 +434,46 @@ class TimesNet(nn.Module):
             return msv.to(device=ref.device, dtype=ref.dtype).expand_as(ref).clone()
         return ref.new_full(ref.shape, self.min_sigma)
 
+    # ---- HIP value embedding (ftn_embed_forward) --------------------------------------
+    def _hip_embed_ok(self, window: torch.Tensor) -> bool:
+        emb = self.embedding
+        if emb is None or emb.embed_norm_mode not in ("decoupled", "none", "layer"):
+            return False
+        if emb.embed_norm_mode == "layer" and not (isinstance(emb.norm, nn.LayerNorm) and emb.norm.weight is not None
+                                                   and emb.norm.bias is not None):
+            return False
+        return (window.is_cuda and window.dtype == torch.float32
+                and not (torch.is_grad_enabled() and (window.requires_grad or emb.value_embedding.weight.requires_grad))
+                and not (self.training and self.dropout > 0.0)
+                and self.d_model % 4 == 0 and self.d_model <= 128
+                and window.stride(2) == 1 and window.stride(1) == window.size(2))
+
+    def _embed_hip(self, window, mark, coeff, cb) -> torch.Tensor:
+        """DataEmbedding.forward with the context front-end folded in: one pass over the window,
+        ``x W^T + add`` where ``add`` carries bias + positional / time-feature term + the temporal
+        context and constant bias pushed through W (reference :1958-1996, :1283-1325)."""
+        from .. import runtime
+
+        emb = self.embedding
+        L = window.size(1)
+        wv = emb.value_embedding.weight.detach()
+        aux = emb.position_embedding(window[:1])                             # [1, L, d]
+        if emb.temporal_embedding is not None and mark is not None:
+            aux = aux + emb.temporal_embedding(mark)                         # [B, L, d]
+        if emb.embed_norm_mode == "decoupled":
+            aux = emb.gate.to(aux.dtype) * _norm(emb.aux_norm, aux)
+        add = aux + emb.value_embedding.bias.detach()
+        if coeff is not None:
+            add = add + self.temporal_context.project(coeff.detach().float(), L, wv)
+        if cb is not None:
+            add = add + torch.matmul(cb.detach().float(), wv.t()).unsqueeze(1)
+        norm = None
+        if emb.embed_norm_mode == "layer":
+            norm = (emb.norm.weight.detach().float().contiguous(), emb.norm.bias.detach().float().contiguous(),
+                    emb.norm.eps)
+        self._last_embed_backend = "hip"
+        return runtime.embed_forward(window, wv, add.detach().float().contiguous(), norm)
+
     # ---- HIP heads (ftn_head_forward) ----------------------------------------------
     def _hip_heads_ok(self, seq: torch.Tensor, window: torch.Tensor) -> bool:
         params = (self.forecast_time_proj.weight, self.mu_head.weight, self.sigma_head.weight)
@@ -455,12 +503,23 @@ class TimesNet(nn.Module):
             self.sigma_head.weight.detach(), self.sigma_head.bias.detach(), window[:, -hist:, :], hist, late_c,
             floor_vec, self.min_sigma)
         self._last_head_backend = "hip"
+        self._pending_bad = bad
+        if not self._defer_checks:
+            self.check_outputs()
+        return rate, dispersion
+
+    def check_outputs(self) -> None:
+        """Raise the reference's RuntimeError (:2095-2098) if the last HIP head call produced a rate or
+        dispersion that is not finite and > 0.  Reads one int32 from the device (synchronises); called by
+        ``forward`` itself unless ``_defer_checks`` is set (HIP-graph capture, ``graph.GraphedForward``)."""
+        bad, self._pending_bad = self._pending_bad, None
+        if bad is None:
+            return
         flag = int(bad.item())
         if flag & 1:
             raise RuntimeError("Predicted rate must be finite and strictly positive")
         if flag & 2:
             raise RuntimeError("Predicted dispersion must be finite and strictly positive")
-        return rate, dispersion
 
     # ---- forward ------------------------------------------------------------------
     def forward(self, x: torch.Tensor, x_mark: Optional[torch.Tensor] = None,
@@ -523,22 +582,28 @@ class TimesNet(nn.Module):
                 self._series_id_reference = ids[0].detach().clone()
             parts.append(self.series_embedding(ids.to(device=window.device, dtype=torch.long)))
 
-        ctx = None
+        ctx = coeff = cb = None
+        fused_embed = self._hip_embed_ok(window)
         if parts:
             ctx = torch.cat(parts, dim=-1)
             if self.context_norm is not None:
                 ctx = _norm(self.context_norm, ctx)
             if self.use_zero_mean_context and self.context_coeff is not None and self.temporal_context is not None:
                 coeff = self.context_coeff(ctx.to(self.context_coeff.weight.dtype))
-                signal = self.temporal_context(coeff, L)              # HIP LRTC kernel on ROCm tensors
-                if signal.ndim != 3 or signal.shape != (Bc,) + tuple(feats_in.shape[1:]):
-                    raise RuntimeError("Temporal context must align with the [B, L, N] input")
-                feats_in = feats_in + signal.to(feats_in.dtype)
+                if not fused_embed:
+                    signal = self.temporal_context(coeff, L)          # HIP LRTC kernel on ROCm tensors
+                    if signal.ndim != 3 or signal.shape != (Bc,) + tuple(feats_in.shape[1:]):
+                        raise RuntimeError("Temporal context must align with the [B, L, N] input")
+                    feats_in = feats_in + signal.to(feats_in.dtype)
             if self.use_constant_context_bias and self.context_proj is not None:
                 cb = self.context_proj(ctx.to(self.context_proj.weight.dtype)).squeeze(-1)
-                feats_in = feats_in + cb.to(feats_in.dtype).unsqueeze(1)
+                if not fused_embed:
+                    feats_in = feats_in + cb.to(feats_in.dtype).unsqueeze(1)
 
-        seq = self.embedding(feats_in, mark)
+        if fused_embed:
+            seq = self._embed_hip(window, mark, coeff, cb)
+        else:
+            seq = self.embedding(feats_in, mark)
         if seq.ndim != 3 or seq.size(1) != self.input_len or seq.size(-1) != self.d_model:
             raise RuntimeError("Embedding output must have shape [B, input_len, d_model]")
 

@@ -572,6 +572,20 @@ class LowRankTemporalContext(nn.Module):
         return ctx if add_to is None else add_to + ctx
 
 
+def _lrtc_project(self, coeff: torch.Tensor, length: int, weight: torch.Tensor) -> torch.Tensor:
+    """``forward(coeff, length) @ weight.T`` without forming the [B, length, N] context: the map is
+    linear, so ``scale * (basis - mean_l basis) @ (coeff^T weight^T)`` -> [B, length, D] (the
+    value-embedding kernel adds it to ``x @ weight.T``)."""
+    basis = self._basis(length, coeff)
+    basis = basis - basis.mean(dim=0, keepdim=True)                    # the forward's second mean removal
+    q = torch.einsum("bnr,dn->brd", coeff, weight)                      # [B, R, D]
+    self._last_backend = "fused"
+    return torch.matmul(basis, q) * self.scale.to(device=coeff.device, dtype=coeff.dtype)
+
+
+LowRankTemporalContext.project = _lrtc_project
+
+
 # The model shell (TimesNet, DataEmbedding, PositionalEmbedding, RMSNorm) lives in shell.py; it is
 # reachable from here as well so that ``from ...models.timesnet import TimesNet`` keeps working.
 _SHELL_NAMES = ("TimesNet", "DataEmbedding", "PositionalEmbedding", "RMSNorm")

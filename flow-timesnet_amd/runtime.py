@@ -199,6 +199,28 @@ def head_forward(hidden: torch.Tensor, w_mu: torch.Tensor, b_mu: torch.Tensor, w
     return rate, disp, bad
 
 
+def embed_forward(window: torch.Tensor, weight: torch.Tensor, add, norm=None) -> torch.Tensor:
+    """``window`` [B,L,N] fp32 view with contiguous rows; ``weight`` [D,N]; ``add`` None or contiguous
+    [1|B,L,D]; ``norm`` None or ``(gamma, beta, eps)``.  Returns [B,L,D]."""
+    lib = _lib.load()
+    B, L, N = window.shape
+    D = weight.shape[0]
+    if window.stride(2) != 1 or window.stride(1) != N:
+        raise ValueError("window rows must be contiguous")
+    add_bs = 0
+    if add is not None:
+        if add.shape[-2:] != (L, D) or not add.is_contiguous():
+            raise ValueError("add must be contiguous [1|B, L, D]")
+        add_bs = L * D if add.dim() == 3 and add.shape[0] == B and B > 1 else 0
+    out = torch.empty(B, L, D, dtype=torch.float32, device=window.device)
+    g, b, eps = norm if norm is not None else (None, None, 0.0)
+    check(lib.ftn_embed_forward(_ptr(window), window.stride(0) if B > 1 else 0, B, L, N, _ptr(weight), D,
+                                _ptr(add) if add is not None else None, add_bs,
+                                _ptr(g) if g is not None else None, _ptr(b) if b is not None else None, float(eps),
+                                _ptr(out), _stream(window.device)), "ftn_embed_forward")
+    return out
+
+
 # ------------------------------------------------------------------ LRTC
 def lrtc_forward(coeff: torch.Tensor, L: int, scale: torch.Tensor, x: torch.Tensor | None) -> torch.Tensor:
     lib = _lib.load()

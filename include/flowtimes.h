@@ -169,6 +169,16 @@ int ftn_head_forward(const float* hidden_dev, long long rows, int S, int D, int 
                      long long late_bstride, const float* floor_vec_dev_or_null, float floor_scalar,
                      float* rate_dev, float* disp_dev, int* bad_flag_dev, void* stream);
 
+/* Value embedding of DataEmbedding.forward (:1283-1325) with everything row-linear folded into `add`:
+ *   out[b][l][:] = x[b][l][:] W^T + add[b?][l][:]      (+ LayerNorm over D when gamma/beta are given)
+ * x: the [B, L, N] input window (rows contiguous, batch stride x_bstride elements); W: nn.Linear weight
+ * [D][N]; add: optional [L][D] (add_bstride 0) or [B][L][D] holding bias + positional/time-feature term
+ * (+ the low-rank temporal context and constant context bias pushed through W, :1958-1996, so the
+ * [B, L, N] context tensor is never written).  D must be a multiple of 4, <= 128. */
+int ftn_embed_forward(const float* x_dev, long long x_bstride, int B, int L, int N, const float* w_dev, int D,
+                      const float* add_dev_or_null, long long add_bstride, const float* ln_gamma_dev_or_null,
+                      const float* ln_beta_dev_or_null, float ln_eps, float* out_dev, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------- */
 /* hipEvent brackets around the 6 stages (A pw-in, B conv, C fused pointwise chain,
  * D conv, E pw-out, F combine) of every following ftn_timesblock_forward call (up to

@@ -303,3 +303,21 @@ def model_heads(hidden: torch.Tensor, w_mu: torch.Tensor, b_mu: torch.Tensor, w_
     sig = F.softplus(F.linear(hidden, w_sigma, b_sigma).float(), beta=1.0, threshold=20)
     floor_t = floor if isinstance(floor, torch.Tensor) else torch.full_like(sig, float(floor))
     return rate, sig + floor_t + 1e-6
+
+
+def embed_front(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, aux_term: torch.Tensor,
+                signal: Optional[torch.Tensor] = None, cbias: Optional[torch.Tensor] = None,
+                ln: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None) -> torch.Tensor:
+    """Context front-end + DataEmbedding.forward (reference :1958-1996, :1283-1325):
+    ``feats = x + signal + cbias[:, None, :]`` (temporal context, constant context bias),
+    ``value = Linear(feats)``, ``out = value + aux_term`` where ``aux_term`` is ``gate * LayerNorm(aux)``
+    ("decoupled") or ``aux`` itself; ``ln`` = the "layer" mode's LayerNorm over the sum."""
+    feats = x
+    if signal is not None:
+        feats = feats + signal
+    if cbias is not None:
+        feats = feats + cbias.unsqueeze(1)
+    out = F.linear(feats, w, b) + aux_term
+    if ln is not None:
+        out = F.layer_norm(out, (out.shape[-1],), ln[0], ln[1], ln[2])
+    return out

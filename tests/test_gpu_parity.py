@@ -291,9 +291,9 @@ def test_full_model_matches_reference(name, manifest, golden, ftn, dev):
     with torch.inference_mode():
         rate, disp = model(torch.from_numpy(g["x"]).to(dev), **kw)
     assert all(b._last_backend == "hip" for b in model.blocks)
-    assert model._last_head_backend == "hip"
+    assert model._last_head_backend == "hip" and model._last_embed_backend == "hip"
     if model.temporal_context is not None:
-        assert model.temporal_context._last_backend == "hip"
+        assert model.temporal_context._last_backend == "fused"
     assert model.period_selector.last_selected_periods.tolist() == g["periods"].tolist()
     np.testing.assert_allclose(rate.cpu().numpy(), g["rate"], rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(disp.cpu().numpy(), g["dispersion"], rtol=RTOL, atol=ATOL)
@@ -413,3 +413,90 @@ def test_heads_flag_bad_outputs(ftn, dev):
     xin[0, -1, 0] = float("inf")
     with torch.inference_mode(), pytest.raises(RuntimeError, match="rate must be finite"):
         model(xin)
+
+
+# ---- value embedding with the context front-end folded in (reference :1958-1996, :1283-1325) ----
+@pytest.mark.parametrize("B,L,N,D,add_b,ln,T", [
+    (3, 24, 5, 8, "shared", False, 24),       # ragged N: scalar loads
+    (2, 336, 512, 64, "shared", False, 340),  # headline shape of one window pair, window = view into a longer x
+    (4, 40, 72, 128, "batch", True, 40),      # d_model 128, per-sample add, LayerNorm epilogue
+    (5, 17, 200, 24, "batch", True, 17),      # rows not a multiple of the tile, d_model not a multiple of 16
+    (1, 50, 64, 16, None, False, 50),
+])
+def test_embed_matches_oracle(B, L, N, D, add_b, ln, T, ftn, dev):
+    g = torch.Generator().manual_seed(L * 7 + N)
+    x = torch.randn(B, T, N, generator=g)
+    w = torch.randn(D, N, generator=g) / N ** 0.5
+    bias = torch.randn(D, generator=g)
+    aux = None if add_b is None else torch.randn(B if add_b == "batch" else 1, L, D, generator=g)
+    lnp = (torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g), 1e-5) if ln else None
+    win = x[:, -L:, :]
+    want = orc.embed_front(win, w, bias, aux if aux is not None else torch.zeros(1, L, D), ln=lnp)
+    add = bias.view(1, 1, D).expand(1, L, D) if aux is None else aux + bias
+    to = lambda t: t.to(dev)
+    out = ftn.runtime.embed_forward(to(x)[:, -L:, :], to(w), to(add.contiguous()),
+                                    None if lnp is None else (to(lnp[0]), to(lnp[1]), lnp[2]))
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_embed_context_fold_matches_oracle(ftn, dev):
+    """The temporal context and the constant context bias enter through ``add`` (pushed through W)
+    instead of being added to x first: same result as the reference order of operations."""
+    B, L, N, D, R = 3, 48, 20, 16, 4
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, L, N, generator=g)
+    w, bias = torch.randn(D, N, generator=g) / N ** 0.5, torch.randn(D, generator=g)
+    coeff = torch.randn(B, N, R, generator=g)
+    cb = 0.3 * torch.randn(B, N, generator=g)
+    aux = torch.randn(1, L, D, generator=g)
+    lrtc = ftn.models.LowRankTemporalContext(R, 0.05)
+    signal = orc.lrtc_forward(coeff, L, torch.tensor(0.05))
+    want = orc.embed_front(x, w, bias, aux, signal=signal, cbias=cb)
+    lrtc = lrtc.to(dev)
+    with torch.inference_mode():
+        add = aux.to(dev) + bias.to(dev) + lrtc.project(coeff.to(dev), L, w.to(dev)) \
+            + torch.matmul(cb.to(dev), w.to(dev).t()).unsqueeze(1)
+        out = ftn.runtime.embed_forward(x.to(dev), w.to(dev), add.contiguous(), None)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+
+
+# ---- HIP-graph replay of whole forwards --------------------------------------------------------
+def test_graphed_model_forward_matches_eager_and_reference(manifest, golden, ftn, dev):
+    case, g = manifest["m_context"], golden("m_context")
+    model, kw = _model_from_fixture(ftn, case, g, dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    with torch.inference_mode():
+        rate_e, disp_e = model(x, **kw)
+    gf = ftn.graph.GraphedForward(model, x, **kw)
+    rate, disp = gf(x, **kw)
+    assert torch.equal(rate, rate_e) and torch.equal(disp, disp_e)
+    np.testing.assert_allclose(rate.cpu().numpy(), g["rate"], rtol=RTOL, atol=ATOL)
+    assert model.period_selector.last_selected_periods.tolist() == g["periods"].tolist()
+    # new data through the same graph: period selection happens on the device inside the replay
+    x2 = torch.roll(x, 3, dims=1) * 1.5
+    with torch.inference_mode():
+        want = model(x2, **kw)
+    got = gf(x2, **kw)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # the deferred finite-positive check still raises
+    x3 = x.clone()
+    x3[0, -1, 0] = float("inf")
+    with pytest.raises(RuntimeError, match="rate must be finite"):
+        gf(x3, **kw)
+
+
+def test_graphed_block_forward(ftn, dev):
+    case = dict(hyper="pipeline", C=32, seed=5)
+    blk, P, ks, act = _block(ftn, case, dev)
+    blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(3, 96)
+    x = torch.from_numpy(ftn.synth.make_input(4, 96, 32, seed=1, planted=(24, 12, 8))).to(dev)
+    gf = ftn.graph.GraphedForward(blk, x)
+    y = gf(x).clone()
+    with torch.inference_mode():
+        want = blk(x)
+    assert torch.equal(y, want)
+    x2 = torch.from_numpy(ftn.synth.make_input(4, 96, 32, seed=2, planted=(16, 6, 32))).to(dev)
+    with torch.inference_mode():
+        want2 = blk(x2)
+    assert torch.equal(gf(x2), want2)
+    assert not torch.equal(want2, want)
