@@ -128,22 +128,37 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// GELU(v) = 0.5 v (1 + erf(v/sqrt2)) via erfc(z) ~= poly(t) exp(-z^2), t = 1/(1+pz)
-// (Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7).  Written in the erfc form so the
-// negative tail keeps its relative accuracy: v >= 0: v - 0.5 v E ; v < 0: 0.5 v E.
-// Max abs error vs fp64 GELU over [-10,10]: 5.3e-7 (libm erff-based fp32: 6.8e-7).
-__device__ __forceinline__ float gelu_erf(float v) {
-  const float z = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp), not an IEEE divide
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float E = p * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);  // raw v_exp_f32; underflow -> 0 is right
-  const float hv = 0.5f * v;
-  return v >= 0.0f ? fmaf(-hv, E, v) : hv * E;
+// GELU(v) = 0.5 v (1 + erf(v/sqrt2)) = max(v,0) - |v| * (0.5 erfc(|v|/sqrt2)), with
+// erfc(z) ~= poly(t) exp(-z^2), t = 1/(1+pz) (Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7).
+// The erfc form keeps the negative tail relatively accurate and needs no compare/select; the 0.5
+// is folded into the polynomial coefficients and 1/sqrt2 into p and the exponent scale.
+// Max abs error vs fp64 GELU over [-10,10]: 3.3e-7 (libm erff-based fp32: 6.8e-7).
+// VALU and MFMA work of a SIMD serialise on gfx950 (tools/ubench/mfma_valu.hip), so the instruction
+// count matters: evaluated on pairs so the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 -
+// 7.5 full-rate instructions + v_rcp_f32 + v_exp_f32 per value.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 gelu_erf2(f2 v) {
+  constexpr float PZ = 0.3275911f * 0.70710678118654752440f;
+  constexpr float KE = 0.84932180028801904272f;          // sqrt(0.5 * log2(e)): exp(-z^2) = exp2(-(|v| KE)^2)
+  f2 t, w, e, r;
+  t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(v.x), PZ, 1.0f));   // v_rcp_f32 (1 ulp), not an IEEE divide
+  t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(v.y), PZ, 1.0f));
+  f2 p = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+  p = p * t + (0.5f * 1.421413741f);
+  p = p * t + (0.5f * -0.284496736f);
+  p = p * t + (0.5f * 0.254829592f);
+  p = p * t;
+  w.x = fabsf(v.x) * KE;
+  w.y = fabsf(v.y) * KE;
+  w = w * w;
+  e.x = __builtin_amdgcn_exp2f(-w.x);                         // raw v_exp_f32; underflow -> 0 is right
+  e.y = __builtin_amdgcn_exp2f(-w.y);
+  p = p * e;
+  r.x = fmaf(-fabsf(v.x), p.x, fmaxf(v.x, 0.0f));
+  r.y = fmaf(-fabsf(v.y), p.y, fmaxf(v.y, 0.0f));
+  return r;
 }
+__device__ __forceinline__ float gelu_erf(float v) { return gelu_erf2(f2{v, v}).x; }
 // ---- bf16x3 split arithmetic -------------------------------------------------------
 // An fp32 value is carried as three bf16 pieces (hi + mid + lo = 24 mantissa bits); a
 // product a*b is formed on the bf16 matrix pipe as the six partial products whose weight
@@ -209,7 +224,12 @@ __device__ __forceinline__ float act_fn(float v) {
 template <int ACT>
 __device__ __forceinline__ f4 act4(f4 v) {
   f4 r;
-  r.x = act_fn<ACT>(v.x); r.y = act_fn<ACT>(v.y); r.z = act_fn<ACT>(v.z); r.w = act_fn<ACT>(v.w);
+  if (ACT == 1) {
+    r.x = act_fn<ACT>(v.x); r.y = act_fn<ACT>(v.y); r.z = act_fn<ACT>(v.z); r.w = act_fn<ACT>(v.w);
+  } else {
+    const f2 lo = gelu_erf2(f2{v.x, v.y}), hi = gelu_erf2(f2{v.z, v.w});
+    r.x = lo.x; r.y = lo.y; r.z = hi.x; r.w = hi.y;
+  }
   return r;
 }
 #endif

@@ -474,22 +474,26 @@ __device__ __forceinline__ void split_pieces(const float (&v)[8], bf8 (&out)[NS]
   }
 }
 
-template <int ACT, bool XVEC, int OTM, bool EXACT, int NS>
-__global__ __launch_bounds__(512) void k_mlp_bf(MlpBfArgs a) {
+// NW = waves per workgroup.  NW = 8: one 256-pixel workgroup per CU, chunk weights double-buffered.
+// NW = 4: 128-pixel workgroups with a single weight buffer (2 x 66 KB would not fit twice), two per CU:
+// VALU and MFMA work of a SIMD serialise on gfx950 (tools/ubench/mfma_valu.hip), so what a second
+// workgroup buys is cover for the first one's prologue loads, chunk barriers, DMA waits and stores.
+template <int ACT, bool XVEC, int OTM, bool EXACT, int NS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
   constexpr int NPX = 2;
   extern __shared__ __attribute__((aligned(16))) char wlb[];
   const FtnDesc* __restrict__ d = a.desc;
   const int N = a.B * d->total_px;
   stamp(a.dbg, a.dbg_cap, blockIdx.x, 0);
-  if ((int)(blockIdx.x * 8 * 16 * NPX) >= N) return;
+  if ((int)(blockIdx.x * NW * 16 * NPX) >= N) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int n0 = (blockIdx.x * 8 + wave) * (16 * NPX);
+  const int n0 = (blockIdx.x * NW + wave) * (16 * NPX);
   const bool active = n0 < N;
   const int bufsz = a.per_chunk * 3 * 1024;
   auto dma_chunk = [&](int hc, int buf) {
     const __bf16* __restrict__ src = a.cfrag + (size_t)hc * a.per_chunk * 3 * 512;
-    for (int piece = wv; piece < a.per_chunk * 3; piece += 8)
+    for (int piece = wv; piece < a.per_chunk * 3; piece += NW)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
                                        (__attribute__((address_space(3))) void*)(wlb + (size_t)buf * bufsz + (size_t)piece * 1024),
                                        16, 0, 0);
@@ -497,8 +501,9 @@ __global__ __launch_bounds__(512) void k_mlp_bf(MlpBfArgs a) {
   dma_chunk(0, 0);
   // biases of both hidden layers, zero-padded to whole chunks, in LDS behind the weight buffers
   const int FPc = a.n_hchunks * 32;
-  float* __restrict__ bias_l = (float*)(wlb + 2 * (size_t)bufsz);
-  for (int i = threadIdx.x; i < 2 * FPc; i += 512) {
+  constexpr int NBUF = NW == 8 ? 2 : 1;
+  float* __restrict__ bias_l = (float*)(wlb + NBUF * (size_t)bufsz);
+  for (int i = threadIdx.x; i < 2 * FPc; i += NW * 64) {
     const int c = i < FPc ? i : i - FPc;
     bias_l[i] = c < a.FP ? (i < FPc ? a.bo[c] : a.br[c]) : 0.f;
   }
@@ -545,11 +550,11 @@ __global__ __launch_bounds__(512) void k_mlp_bf(MlpBfArgs a) {
   stamp(a.dbg, a.dbg_cap, blockIdx.x, 1);
   for (int hc = 0; hc < a.n_hchunks; ++hc) {
     if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 2);
-    const char* __restrict__ wl = wlb + (size_t)(hc & 1) * bufsz + lane * 16;
+    const char* __restrict__ wl = wlb + (size_t)(NBUF == 2 ? (hc & 1) : 0) * bufsz + lane * 16;
     // request the next chunk right away: its buffer was last read before the barrier that
     // opened this chunk, and nothing below waits on vmcnt until the closing barrier.  The
     // biases come from LDS (staged once in the prologue), not from global memory.
-    if (hc + 1 < a.n_hchunks) dma_chunk(hc + 1, (hc + 1) & 1);
+    if (NBUF == 2 && hc + 1 < a.n_hchunks) dma_chunk(hc + 1, (hc + 1) & 1);
     f4 bo_t[2], br_t[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -621,10 +626,12 @@ __global__ __launch_bounds__(512) void k_mlp_bf(MlpBfArgs a) {
       for (int u = 0; u < NPX; ++u) h[1][u] = chain_bf<NS>(fb, xp[1][u], h[1][u]);
       gelu_u(0, 1, false);
       __builtin_amdgcn_sched_barrier(0);
+      if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 4);
       // ---- G2(t1,u0), split(u0)   (the only VALU stretch without an MFMA partner)
       gelu_u(1, 0, false);
       split_u(0);
       __builtin_amdgcn_sched_barrier(0);
+
       // ---- L2(u0) + G2(t1,u1), split(u1): fragments f = 8 .. 8+n_ot-1, ping-pong fa/fb
 #pragma unroll
       for (int o = 0; o < OTM; ++o) {
@@ -636,6 +643,7 @@ __global__ __launch_bounds__(512) void k_mlp_bf(MlpBfArgs a) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 6);
       // ---- L2(u1): the wrap-around prefetch above left fragment 8 in the next register set
 #pragma unroll
       for (int o = 0; o < OTM; ++o) {
@@ -646,7 +654,13 @@ __global__ __launch_bounds__(512) void k_mlp_bf(MlpBfArgs a) {
         }
       }
     }
+    if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 7);
+    if (hc == 1 && a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(a.dbg, a.dbg_cap, blockIdx.x, 5); }
     __syncthreads();
+    if (NBUF == 1 && hc + 1 < a.n_hchunks) {     // single buffer: refill once every wave has left the chunk
+      dma_chunk(hc + 1, 0);
+      __syncthreads();
+    }
   }
   stamp(a.dbg, a.dbg_cap, blockIdx.x, 3);
   if (!active) return;
@@ -1712,17 +1726,33 @@ static int launch_mlp(const MlpArgs& ma, bool xvec, long long Nmax, hipStream_t 
   return xvec ? launch_mlp_x<ACT, true>(ma, Nmax, st) : launch_mlp_x<ACT, false>(ma, Nmax, st);
 }
 
-template <int ACT, bool XVEC, int OTM, bool EXACT, int NS>
-static int launch_mlp_bf_t(MlpBfArgs ma, long long Nmax, hipStream_t st) {
+template <int ACT, bool XVEC, int OTM, bool EXACT, int NS, int NW>
+static int launch_mlp_bf_w(MlpBfArgs ma, long long Nmax, hipStream_t st) {
   ma.dbg = (g_stamp_which & 2) ? g_stamp_buf : nullptr; ma.dbg_cap = g_stamp_cap;
-  const size_t lds = (size_t)ma.per_chunk * 3 * 1024 * 2 + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)k_mlp_bf<ACT, XVEC, OTM, EXACT, NS>,
+  const size_t lds = (size_t)ma.per_chunk * 3 * 1024 * (NW == 8 ? 2 : 1) + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)k_mlp_bf<ACT, XVEC, OTM, EXACT, NS, NW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_bf): %s", hipGetErrorString(e)); return (int)e; }
-  const int nblk = (int)((Nmax + 255) / 256);
-  hipLaunchKernelGGL((k_mlp_bf<ACT, XVEC, OTM, EXACT, NS>), dim3(nblk), dim3(512), lds, st, ma);
+  const int px_wg = NW * 32;
+  const int nblk = (int)((Nmax + px_wg - 1) / px_wg);
+  hipLaunchKernelGGL((k_mlp_bf<ACT, XVEC, OTM, EXACT, NS, NW>), dim3(nblk), dim3(NW * 64), lds, st, ma);
   FTN_CHECK_LAUNCH();
   return 0;
+}
+
+static int mlp_bf_waves() {
+  static int nw = 0;
+  if (nw == 0) {
+    const char* e = getenv("FLOWTIMES_MLP_WAVES");
+    nw = (e && atoi(e) == 8) ? 8 : 4;
+  }
+  return nw;
+}
+
+template <int ACT, bool XVEC, int OTM, bool EXACT, int NS>
+static int launch_mlp_bf_t(const MlpBfArgs& ma, long long Nmax, hipStream_t st) {
+  if (mlp_bf_waves() == 8) return launch_mlp_bf_w<ACT, XVEC, OTM, EXACT, NS, 8>(ma, Nmax, st);
+  return launch_mlp_bf_w<ACT, XVEC, OTM, EXACT, NS, 4>(ma, Nmax, st);
 }
 
 template <int ACT, int NS>
