@@ -500,3 +500,38 @@ def test_graphed_block_forward(ftn, dev):
         want2 = blk(x2)
     assert torch.equal(gf(x2), want2)
     assert not torch.equal(want2, want)
+
+
+def test_pipeline_shaped_call_hip_vs_cpu_mirror(ftn, dev):
+    """How the reference's predict_once calls the model (predict.py:797-966, one series per batch row):
+    x[B=193, L=28, N=1] with per-sample static features [B,1,F] and ids [B,1].  The CPU mirror is pinned to
+    the reference by tests/test_predict_pipeline_dropin.py; here the HIP path must reproduce it."""
+    B, L, H = 193, 28, 7
+    cfg = dict(input_len=L, pred_len=H, d_model=16, d_ff=32, n_layers=2, k_periods=2, kernel_set=[3, 5], dropout=0.0,
+               activation="gelu", mode="direct", bottleneck_ratio=2.0, id_embed_dim=6, static_proj_dim=5,
+               use_zero_mean_context=True, context_rank=3, context_scale=0.05, use_constant_context_bias=True)
+    g = torch.Generator().manual_seed(11)
+    t = torch.arange(L, dtype=torch.float32).view(1, L, 1)
+    x = torch.rand(B, L, 1, generator=g) * 5.0 + 2.0 * torch.sin(2 * torch.pi * t / 7.0)
+    static = torch.randn(B, 1, 4, generator=g)
+    ids = torch.arange(B).view(B, 1)
+    torch.manual_seed(0)
+    cpu = ftn.models.TimesNet(**cfg).eval()
+    warm = dict(series_static=static[:1, 0], series_ids=torch.tensor([B - 1]))   # max id sizes the table (:1437)
+    with torch.no_grad():
+        cpu(torch.zeros(1, L, 1), **warm)
+        for p in cpu.parameters():
+            if float(p.abs().sum()) == 0.0:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+        want_r, want_d = cpu(x, series_static=static, series_ids=ids)
+    gpu = ftn.models.TimesNet(**cfg).eval()
+    with torch.no_grad():
+        gpu(torch.zeros(1, L, 1, device=dev), **{k: v.to(dev) for k, v in warm.items()})
+    gpu.load_state_dict(cpu.state_dict(), strict=True)
+    with torch.inference_mode():
+        rate, disp = gpu(x.to(dev), series_static=static.to(dev), series_ids=ids.to(dev))
+    assert all(b._last_backend == "hip" for b in gpu.blocks)
+    assert gpu._last_head_backend == "hip" and gpu._last_embed_backend == "hip"
+    assert gpu.period_selector.last_selected_periods.tolist() == cpu.period_selector.last_selected_periods.tolist()
+    np.testing.assert_allclose(rate.cpu().numpy(), want_r.numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(disp.cpu().numpy(), want_d.numpy(), rtol=RTOL, atol=ATOL)
