@@ -64,11 +64,21 @@ __device__ __forceinline__ Px decode_px(const FtnDesc* __restrict__ d, const flo
   p.ok = n < N;
   p.n = p.ok ? n : N - 1;
   const int G = d->n_groups;
-  int g = 0;
-  for (int gg = 1; gg < G; ++gg)
-    if (p.n >= B * d->g_px_off[gg]) g = gg;
-  const int P = d->g_px_off[g + 1] - d->g_px_off[g];
-  const int rem = p.n - B * d->g_px_off[g];
+  // the whole prefix table in one batch of scalar loads (fixed trip count), then a select chain:
+  // a data-dependent loop here costs one scalar-memory round trip per group on every workgroup's
+  // critical path
+  int off[FTN_KMAX + 1];
+#pragma unroll
+  for (int i = 0; i <= FTN_KMAX; ++i) off[i] = d->g_px_off[i];
+  int lo = 0, hi = off[1];
+#pragma unroll
+  for (int gg = 1; gg < FTN_KMAX; ++gg) {
+    const bool in = gg < G && p.n >= B * off[gg];
+    lo = in ? off[gg] : lo;
+    hi = in ? off[gg + 1] : hi;
+  }
+  const int P = hi - lo;
+  const int rem = p.n - B * lo;
   const int b = rem / P, t = rem - b * P;
   p.xrow = (t < L) ? x + ((size_t)b * L + t) * C : nullptr;
   return p;
@@ -491,13 +501,40 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
   const int n0 = (blockIdx.x * NW + wave) * (16 * NPX);
   const bool active = n0 < N;
   const int bufsz = a.per_chunk * 3 * 1024;
-  auto dma_chunk = [&](int hc, int buf) {
+  // fragments [f_lo, f_hi) of chunk hc -> the same slots of buffer `buf`
+  auto dma_frags = [&](int hc, int buf, int f_lo, int f_hi) {
     const __bf16* __restrict__ src = a.cfrag + (size_t)hc * a.per_chunk * 3 * 512;
-    for (int piece = wv; piece < a.per_chunk * 3; piece += NW)
+    for (int piece = 3 * f_lo + wv; piece < 3 * f_hi; piece += NW)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
                                        (__attribute__((address_space(3))) void*)(wlb + (size_t)buf * bufsz + (size_t)piece * 1024),
                                        16, 0, 0);
   };
+  auto dma_chunk = [&](int hc, int buf) { dma_frags(hc, buf, 0, a.per_chunk); };
+  // Prologue order matters: vmcnt retires in order, so whatever is issued before the pixel loads is
+  // waited for with them.  Decode first (scalar loads only), then this wave's m / x rows, and only then
+  // the chunk-0 weight DMA and the bias staging, which are not needed before the first barrier.
+  Px px[NPX];
+#pragma unroll
+  for (int u = 0; u < NPX; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
+  const int CP = a.CP;
+  const int nsKM = a.nsKM, nsCP = a.nsCP, n_ot = EXACT ? OTM : a.n_ot;
+  const int kmg = a.KM >> 4;                                  // 16-channel groups of m
+  // B operands that do not depend on the hidden chunk
+  bf8 mp[2][NPX][NS], xp[2][NPX][NS];
+  f4 xraw[2][NPX][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) {
+      const int grp = 2 * s + (qa >> 1);
+      const __bf16* __restrict__ src = a.m + ((size_t)px[u].n * kmg + (grp < kmg ? grp : 0)) * 48 + (qa & 1) * 8;
+#pragma unroll
+      for (int pz = 0; pz < NS; ++pz) mp[s][u][pz] = *(const bf8*)(src + pz * 16);
+      xraw[s][u][0] = s < nsCP ? load_x4<XVEC>(px[u].xrow, 32 * s + 8 * qa, a.C) : f4{0.f, 0.f, 0.f, 0.f};
+      xraw[s][u][1] = s < nsCP ? load_x4<XVEC>(px[u].xrow, 32 * s + 8 * qa + 4, a.C) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
   dma_chunk(0, 0);
   // biases of both hidden layers, zero-padded to whole chunks, in LDS behind the weight buffers
   const int FPc = a.n_hchunks * 32;
@@ -507,34 +544,20 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
     const int c = i < FPc ? i : i - FPc;
     bias_l[i] = c < a.FP ? (i < FPc ? a.bo[c] : a.br[c]) : 0.f;
   }
-  Px px[NPX];
-#pragma unroll
-  for (int u = 0; u < NPX; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
-  const int CP = a.CP;
-  const int nsKM = a.nsKM, nsCP = a.nsCP, n_ot = EXACT ? OTM : a.n_ot;
-  const int kmg = a.KM >> 4;                                  // 16-channel groups of m
-  // B operands that do not depend on the hidden chunk
-  bf8 mp[2][NPX][NS], xp[2][NPX][NS];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
     for (int u = 0; u < NPX; ++u) {
       const int grp = 2 * s + (qa >> 1);
-      const __bf16* __restrict__ src = a.m + ((size_t)px[u].n * kmg + (grp < kmg ? grp : 0)) * 48 + (qa & 1) * 8;
+      if (!(s < nsKM && grp < kmg)) {
 #pragma unroll
-      for (int pz = 0; pz < NS; ++pz) {
-        bf8 v = *(const bf8*)(src + pz * 16);
-        if (!(s < nsKM && grp < kmg)) {
+        for (int pz = 0; pz < NS; ++pz)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
-        }
-        mp[s][u][pz] = v;
+          for (int e = 0; e < 8; ++e) mp[s][u][pz][e] = (__bf16)0.0f;
       }
       float xv[8];
-      const f4 x0 = s < nsCP ? load_x4<XVEC>(px[u].xrow, 32 * s + 8 * qa, a.C) : f4{0.f, 0.f, 0.f, 0.f};
-      const f4 x1 = s < nsCP ? load_x4<XVEC>(px[u].xrow, 32 * s + 8 * qa + 4, a.C) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { xv[e] = x0[e]; xv[4 + e] = x1[e]; }
+      for (int e = 0; e < 4; ++e) { xv[e] = xraw[s][u][0][e]; xv[4 + e] = xraw[s][u][1][e]; }
       split_pieces<NS>(xv, xp[s][u]);
     }
   }
@@ -561,6 +584,23 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
       bo_t[t] = *(const f4*)(bias_l + 16 * (hc * 2 + t) + 4 * qa);
       br_t[t] = *(const f4*)(bias_l + FPc + 16 * (hc * 2 + t) + 4 * qa);
     }
+    f4 h[2][NPX];
+    bf8 hp[NPX][NS];
+    bf8 fa[NS], fb[NS];
+    auto ldfrag = [&](int f, bf8 (&ap)[NS]) {
+#pragma unroll
+      for (int pz = 0; pz < NS; ++pz) ap[pz] = *(const bf8*)(wl + (size_t)(f * 3 + pz) * 1024);
+    };
+    auto gelu_u = [&](int t, int u, bool addbr) {
+      h[t][u] = act4<ACT>(h[t][u]);
+      if (addbr) h[t][u] += br_t[t];
+    };
+    auto split_u = [&](int u) {
+      float hv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { hv[e] = h[0][u][e]; hv[4 + e] = h[1][u][e]; }
+      split_pieces<NS>(hv, hp[u]);
+    };
     if (active) {
       // Statically scheduled chunk (KM <= 64, C <= 64: two K slabs each).  The 8 + 2*n_ot weight
       // fragments are walked in LDS order with a one-step-ahead register prefetch, and the
@@ -569,27 +609,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
       // the two waves of a SIMD run in lockstep between chunk barriers:
       //   f0 f1: L1(t0) | f2 f3: L1(t1) + G1(t0) | f4 f5: R(t0) + G1(t1) | f6 f7: R(t1) + G2(t0)
       //   G2(t1,u0) split(u0) | L2(u0) + G2(t1,u1) split(u1) | L2(u1)
-      f4 h[2][NPX];
-      bf8 hp[NPX][NS];
-      auto ldfrag = [&](int f, bf8 (&ap)[NS]) {
-#pragma unroll
-        for (int pz = 0; pz < NS; ++pz) ap[pz] = *(const bf8*)(wl + (size_t)(f * 3 + pz) * 1024);
-      };
-      auto gelu_u = [&](int t, int u, bool addbr) {
-        h[t][u] = act4<ACT>(h[t][u]);
-        if (addbr) h[t][u] += br_t[t];
-      };
-      auto split_u = [&](int u) {
-        float hv[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { hv[e] = h[0][u][e]; hv[4 + e] = h[1][u][e]; }
-        split_pieces<NS>(hv, hp[u]);
-      };
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < NPX; ++u) h[t][u] = bo_t[t];
-      bf8 fa[NS], fb[NS];
       ldfrag(0, fa);
       // ---- L1(t0)
       ldfrag(1, fb); __builtin_amdgcn_sched_barrier(0);
@@ -626,7 +649,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
       for (int u = 0; u < NPX; ++u) h[1][u] = chain_bf<NS>(fb, xp[1][u], h[1][u]);
       gelu_u(0, 1, false);
       __builtin_amdgcn_sched_barrier(0);
-      if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 4);
       // ---- G2(t1,u0), split(u0)   (the only VALU stretch without an MFMA partner)
       gelu_u(1, 0, false);
       split_u(0);
@@ -643,7 +665,6 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 6);
       // ---- L2(u1): the wrap-around prefetch above left fragment 8 in the next register set
 #pragma unroll
       for (int o = 0; o < OTM; ++o) {
@@ -657,7 +678,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
     if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 7);
     if (hc == 1 && a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(a.dbg, a.dbg_cap, blockIdx.x, 5); }
     __syncthreads();
-    if (NBUF == 1 && hc + 1 < a.n_hchunks) {     // single buffer: refill once every wave has left the chunk
+    if (NBUF == 1 && hc + 1 < a.n_hchunks) {
+      // single buffer: refill once every wave has left the chunk.  (Refilling in halves behind a
+      // mid-chunk barrier hides the DMA but costs more in barrier skew than it saves: measured +5 %.)
       dma_chunk(hc + 1, 0);
       __syncthreads();
     }
@@ -1260,9 +1283,8 @@ __global__ __launch_bounds__(256) void k_resid_ln(const float* __restrict__ x, c
 // Fast path (FAST): K <= 48 and <= 4 output tiles (d_model <= 64, nbr*mid <= 48): the 12
 // weight fragments are group-independent and live in registers; per group the wave only
 // streams its m' and r rows, with the next group's m' rows requested one group ahead.
-template <int ACT, bool XVEC, bool IDENT, bool FAST>
-__global__ __launch_bounds__(256) void k_out(OutArgs a) {
-  constexpr int NPX = 2;
+template <int ACT, bool XVEC, bool IDENT, bool FAST, int NPX = 2>
+__global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
   const FtnDesc* __restrict__ d = a.desc;
   const int total = a.B * a.L;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
@@ -1858,7 +1880,10 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CA;
     const bool fast = CA <= 48 && CP <= 64;
     if (fast) { oa.ln_g = ln_g; oa.ln_b = ln_b; oa.ln_eps = ln_eps; ln_g = nullptr; }   // fused epilogue
-    if (xvec && yvec && fast) hipLaunchKernelGGL((k_out<ACT, true, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
+    static const int out_npx = getenv("FLOWTIMES_OUT_NPX") ? atoi(getenv("FLOWTIMES_OUT_NPX")) : 1;   // 16 px per wave: 3 waves/SIMD
+    if (xvec && yvec && fast && out_npx == 1)
+      hipLaunchKernelGGL((k_out<ACT, true, false, true, 1>), dim3((unsigned)(((long long)B * L + 63) / 64)), dim3(256), 0, st, oa);
+    else if (xvec && yvec && fast) hipLaunchKernelGGL((k_out<ACT, true, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
     else if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
     else if (fast) hipLaunchKernelGGL((k_out<ACT, false, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
     else hipLaunchKernelGGL((k_out<ACT, false, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
