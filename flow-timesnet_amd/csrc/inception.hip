@@ -960,7 +960,10 @@ struct ConvBfArgs {
 #define CBF_NU 3          // 16-pixel units per wave: 8 waves x 3 x 16 >= FTN_TILE_PX
 #define P3_PX_BYTES 96    // one pixel of one 16-channel group in global memory: 3 pieces x 16 bf16
 #define P3_LDS_STRIDE 112 // LDS pixel stride: 96 + 16 pad bytes, so the 16 pixels of a ds_read_b128 lane
-                          // group fall on 16 distinct bank quads (96 would be 2-way conflicted)
+                          // group fall on 16 distinct bank quads (96 would be 2-way conflicted).  PMC still
+                          // reports ~2.6 conflict cycles per LDS instruction here (4.0 cycles conflict-free);
+                          // giving out-of-grid lanes bank-matched zero pixels did not change that, and the
+                          // next coprime stride (144 B) does not fit two region buffers plus the 7x7 weights.
 
 template <int NCO, int NS>
 __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
@@ -1762,18 +1765,10 @@ static int launch_mlp_bf_w(MlpBfArgs ma, long long Nmax, hipStream_t st) {
   return 0;
 }
 
-static int mlp_bf_waves() {
-  static int nw = 0;
-  if (nw == 0) {
-    const char* e = getenv("FLOWTIMES_MLP_WAVES");
-    nw = (e && atoi(e) == 8) ? 8 : 4;
-  }
-  return nw;
-}
-
 template <int ACT, bool XVEC, int OTM, bool EXACT, int NS>
 static int launch_mlp_bf_t(const MlpBfArgs& ma, long long Nmax, hipStream_t st) {
-  if (mlp_bf_waves() == 8) return launch_mlp_bf_w<ACT, XVEC, OTM, EXACT, NS, 8>(ma, Nmax, st);
+  // 4-wave workgroups, two per CU (the 8-wave double-buffered form is kept in the kernel template:
+  // 425 us against 360 us at the bench shape)
   return launch_mlp_bf_w<ACT, XVEC, OTM, EXACT, NS, 4>(ma, Nmax, st);
 }
 
@@ -1880,12 +1875,11 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CA;
     const bool fast = CA <= 48 && CP <= 64;
     if (fast) { oa.ln_g = ln_g; oa.ln_b = ln_b; oa.ln_eps = ln_eps; ln_g = nullptr; }   // fused epilogue
-    static const int out_npx = getenv("FLOWTIMES_OUT_NPX") ? atoi(getenv("FLOWTIMES_OUT_NPX")) : 1;   // 16 px per wave: 3 waves/SIMD
-    if (xvec && yvec && fast && out_npx == 1)
-      hipLaunchKernelGGL((k_out<ACT, true, false, true, 1>), dim3((unsigned)(((long long)B * L + 63) / 64)), dim3(256), 0, st, oa);
-    else if (xvec && yvec && fast) hipLaunchKernelGGL((k_out<ACT, true, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
+    // FAST path: 16 pixels per wave (3 waves/SIMD; with 32 the kernel needs > 256 registers -> 1 wave/SIMD)
+    const unsigned nblk_fast = (unsigned)(((long long)B * L + 63) / 64);
+    if (xvec && yvec && fast) hipLaunchKernelGGL((k_out<ACT, true, false, true, 1>), dim3(nblk_fast), dim3(256), 0, st, oa);
     else if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
-    else if (fast) hipLaunchKernelGGL((k_out<ACT, false, false, true>), dim3(nblk_out), dim3(256), 0, st, oa);
+    else if (fast) hipLaunchKernelGGL((k_out<ACT, false, false, true, 1>), dim3(nblk_fast), dim3(256), 0, st, oa);
     else hipLaunchKernelGGL((k_out<ACT, false, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
     FTN_CHECK_LAUNCH();
     prof_mark(5, st);

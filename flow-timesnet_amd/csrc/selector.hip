@@ -100,6 +100,35 @@ __device__ __forceinline__ float wave_lower_median(const float* __restrict__ row
   return m;
 }
 
+// Four independent <= 64-element sorts interleaved in one instruction stream: the 21 dependent
+// compare-exchange steps of a single sort (each a cross-lane permute) leave the wave waiting on its own
+// latency chain, and every workgroup of the launch reaches this phase at the same time.
+__device__ __forceinline__ void wave_lower_median_x4(const float* __restrict__ r0, const float* __restrict__ r1,
+                                                     const float* __restrict__ r2, const float* __restrict__ r3,
+                                                     int C, int lane, float (&m)[4]) {
+  float v[4];
+  v[0] = lane < C ? r0[lane] : INFINITY;
+  v[1] = lane < C ? r1[lane] : INFINITY;
+  v[2] = lane < C ? r2[lane] : INFINITY;
+  v[3] = lane < C ? r3[lane] : INFINITY;
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int jj = k >> 1; jj > 0; jj >>= 1) {
+      const bool up = (lane & k) == 0;            // k == 64: every lane index is below 64 -> ascending
+      const bool lower = (lane & jj) == 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float other = __shfl_xor(v[r], jj);
+        v[r] = (lower == up) ? fminf(v[r], other) : fmaxf(v[r], other);
+      }
+    }
+  }
+  const int t = (C - 1) >> 1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m[r] = __shfl(v[r], t);
+}
+
 __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, int L, int C,
                                                   const float* __restrict__ tab, int F, int FPAD,
                                                   float* __restrict__ med) {
@@ -172,6 +201,19 @@ __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, i
   }
   __syncthreads();
   const int target = (C - 1) >> 1;  // torch.median == sorted[(C-1)//2]
+  if (C <= 64 && (32 % (4 * nw)) == 0) {
+    for (int fb = wave; fb < 32; fb += 4 * nw) {          // rows fb, fb+nw, fb+2nw, fb+3nw
+      float m[4];
+      wave_lower_median_x4(amp + fb * CS, amp + (fb + nw) * CS, amp + (fb + 2 * nw) * CS, amp + (fb + 3 * nw) * CS, C,
+                           lane, m);
+      if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (f0 + fb + r * nw < F) med[(size_t)b * F + f0 + fb + r * nw] = m[r];
+      }
+    }
+    return;
+  }
   for (int fl = wave; fl < 32; fl += nw) {
     if (f0 + fl >= F) break;
     const float* __restrict__ row = amp + fl * CS;

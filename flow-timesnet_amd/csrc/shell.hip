@@ -231,7 +231,7 @@ struct EmbedArgs {
 // up with columns 16*o + 4*q .. +3 of row j: 64-byte runs per store instruction, and the LayerNorm
 // reduction is in-lane plus two xor-shuffles.
 template <int NO, bool VEC>
-__global__ __launch_bounds__(256) void k_embed_in(EmbedArgs a) {
+__global__ __launch_bounds__(256, NO <= 4 ? 3 : 1) void k_embed_in(EmbedArgs a) {
   constexpr int RT = 2, KC = 64, NFR = NO * 4 * 64;            // f4 fragments per chunk
   constexpr int PER_T = (NFR + 255) / 256;
   __shared__ f4 wl[2][NFR];
