@@ -6,8 +6,12 @@ inception convs + aggregation) over one synthetic batch already resident in HBM.
 Workload (N=1): B=256, L=336, N=512 series (d_model=64 embedded channels,
 d_ff=256, kernels 3/5/7, bottleneck ratio 4, k_periods=5), fp32.  ``series/sec``
 = B*N / t (TimesBlock never sees N: SURVEY finding 2).  With --gpus G every rank
-owns a B=256 shard of a G*256 batch (weak scaling): one [F]-float exchange per
-step for the shared periods, then an all-gather of the outputs (RCCL).
+owns a B=256 shard of a G*256 batch (weak scaling).  The path's one real exchange
+step is timed: the all-gather of the [F] partial batch sums that makes every rank
+select the same periods (RCCL).  Outputs stay batch-sharded, as they do between the
+blocks of a data-parallel model; the optional all-gather of the outputs along B
+(dist.gather_batch, overlapped with the next step) is timed separately and reported
+as ``ms_per_step_with_output_allgather``.
 
 Prints ONE JSON line on rank 0.
 """
@@ -101,6 +105,9 @@ def main() -> None:
         pending = []
 
         def step():
+            return runner(x, gather=False)
+
+        def step_gather():
             # the output all-gather of step i overlaps the compute of step i+1 (at most two in
             # flight); every output is fully assembled on every rank before the clock stops
             out, work = runner(x, gather="async")
@@ -120,6 +127,7 @@ def main() -> None:
         barrier = lambda: dist.barrier()
     else:
         step = lambda: blk(x)
+        step_gather = None
         drain = lambda: None
         barrier = lambda: None
 
@@ -156,10 +164,27 @@ def main() -> None:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             y = step()
-        drain()
         torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
+        ms_sum = (ctypes.c_float * 6)()
+        ncalls = ctypes.c_int(0)
+        pkg.lib.check(lib.ftn_stage_times(ms_sum, 6, ctypes.byref(ncalls)), "ftn_stage_times")
+        lib.ftn_stage_timing(0)
+        ms_gather = None
+        if step_gather is not None:
+            for _ in range(2):
+                step_gather()
+            drain()
+            torch.cuda.synchronize()
+            barrier()
+            g0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_gather()
+            drain()
+            torch.cuda.synchronize()
+            barrier()
+            ms_gather = (time.perf_counter() - g0) * 1e3 / args.steps
     assert blk._last_backend == "hip"
     elapsed = t1 - t0
     if use_dist:
@@ -167,10 +192,10 @@ def main() -> None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    ms_sum = (ctypes.c_float * 6)()
-    ncalls = ctypes.c_int(0)
-    pkg.lib.check(lib.ftn_stage_times(ms_sum, 6, ctypes.byref(ncalls)), "ftn_stage_times")
-    lib.ftn_stage_timing(0)
+        if ms_gather is not None:
+            tg = torch.tensor([ms_gather], dtype=torch.float64, device=dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            ms_gather = float(tg.item())
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * B * NS / (elapsed / args.steps)
 
@@ -224,7 +249,8 @@ def main() -> None:
                                    "same 1e-4 parity tests)",
                        "engine": engine, "other_engine_ms_per_step": alt_ms,
                        "windows_per_s": world * B / (elapsed / args.steps), "periods": periods, "groups": G,
-                       "parallelism": f"batch-shard x{world}" if world > 1 else "single"},
+                       "parallelism": (f"batch-shard x{world}: one all-gather of [F] fp64 partial sums per step, outputs stay sharded"
+                                       if use_dist else "single")},
             "roofline": {"bound": "mfma", "kernel": STAGES[dom], "achieved": achieved, "peak": peak_tf,
                          "unit": "TFLOP/s", "frac": achieved / peak_tf, "traffic": traffic,
                          "flops_per_launch": flops_exec, "avg_launch_ms": stage_ms[dom],
@@ -233,6 +259,8 @@ def main() -> None:
                          "block_executed_tflops": executed / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          "block_nominal_tflops": nominal / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0},
         }
+        if ms_gather is not None:
+            out["ms_per_step_with_output_allgather"] = ms_gather
         if world == 1:
             out["lrtc"] = lrtc_bench(pkg, dev, B, L, NS)
             out["model_forward"] = model_bench(pkg, dev, B, L, NS, C, ks, ratio, K)
