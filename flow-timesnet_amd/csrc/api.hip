@@ -36,3 +36,24 @@ extern "C" int ftn_selftest_mfma(float* out_dev, void* stream) {
   FTN_CHECK_LAUNCH();
   return 0;
 }
+
+// out[i] = the kernels' GELU(in[i]) (ftn_common.h gelu_erf2), for the accuracy test.
+__global__ void k_selftest_gelu(const float* __restrict__ in, float* __restrict__ out, long long n) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f4 v = act4<0>(*(const f4*)(in + i));
+    *(f4*)(out + i) = v;
+  } else {
+    for (long long k = i; k < n; ++k) out[k] = gelu_erf(in[k]);
+  }
+}
+
+extern "C" int ftn_selftest_gelu(const float* in_dev, float* out_dev, long long n, void* stream) {
+  FTN_CHECK_ARG(in_dev && out_dev && n >= 1 && (((uintptr_t)in_dev | (uintptr_t)out_dev) & 15) == 0,
+                "ftn_selftest_gelu: bad arguments");
+  const long long nthr = (n + 3) / 4;
+  hipLaunchKernelGGL(k_selftest_gelu, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in_dev,
+                     out_dev, n);
+  FTN_CHECK_LAUNCH();
+  return 0;
+}

@@ -128,34 +128,28 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// GELU(v) = 0.5 v (1 + erf(v/sqrt2)) = max(v,0) - |v| * (0.5 erfc(|v|/sqrt2)), with
-// erfc(z) ~= poly(t) exp(-z^2), t = 1/(1+pz) (Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7).
-// The erfc form keeps the negative tail relatively accurate and needs no compare/select; the 0.5
-// is folded into the polynomial coefficients and 1/sqrt2 into p and the exponent scale.
-// Max abs error vs fp64 GELU over [-10,10]: 3.3e-7 (libm erff-based fp32: 6.8e-7).
-// VALU and MFMA work of a SIMD serialise on gfx950 (tools/ubench/mfma_valu.hip), so the instruction
-// count matters: evaluated on pairs so the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 -
-// 7.5 full-rate instructions + v_rcp_f32 + v_exp_f32 per value.
+// GELU(v) = 0.5 v (1 + erf(v/sqrt2)) = max(v,0) - a * 2^(-h(a)),  a = |v|,  h(a) = log2(2 / erfc(a/sqrt2)).
+// h is smooth and nearly quadratic, so a degree-6 polynomial (weighted Chebyshev fit on [0, 8], weight =
+// the term a 2^-h itself; a is clamped to 8, beyond which the term is < 1e-14) reproduces the term to
+// 6e-8 and the whole evaluation needs one transcendental (v_exp_f32) instead of v_rcp_f32 + v_exp_f32:
+// max abs error vs fp64 GELU over [-10, 10] 2.9e-7 in fp32 (A&S 7.1.26 erfc form: 3.3e-7; libm erff: 6.8e-7).
+// VALU and MFMA work of a SIMD serialise on gfx950 (tools/ubench/mfma_valu.hip), so the instruction count
+// matters: per value 3.2 full-rate-equivalent pk_fma + v_min + v_max + v_fma + v_exp = ~32 issue cycles.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 gelu_erf2(f2 v) {
-  constexpr float PZ = 0.3275911f * 0.70710678118654752440f;
-  constexpr float KE = 0.84932180028801904272f;          // sqrt(0.5 * log2(e)): exp(-z^2) = exp2(-(|v| KE)^2)
-  f2 t, w, e, r;
-  t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(v.x), PZ, 1.0f));   // v_rcp_f32 (1 ulp), not an IEEE divide
-  t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(v.y), PZ, 1.0f));
-  f2 p = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
-  p = p * t + (0.5f * 1.421413741f);
-  p = p * t + (0.5f * -0.284496736f);
-  p = p * t + (0.5f * 0.254829592f);
-  p = p * t;
-  w.x = fabsf(v.x) * KE;
-  w.y = fabsf(v.y) * KE;
-  w = w * w;
-  e.x = __builtin_amdgcn_exp2f(-w.x);                         // raw v_exp_f32; underflow -> 0 is right
-  e.y = __builtin_amdgcn_exp2f(-w.y);
-  p = p * e;
-  r.x = fmaf(-fabsf(v.x), p.x, fmaxf(v.x, 0.0f));
-  r.y = fmaf(-fabsf(v.y), p.y, fmaxf(v.y, 0.0f));
+  f2 a, e, r;
+  a.x = fminf(fabsf(v.x), 8.0f);
+  a.y = fminf(fabsf(v.y), 8.0f);
+  f2 p = a * -3.262207974330522e-05f + 0.0007656298694200814f;
+  p = p * a + -0.008070714771747589f;
+  p = p * a + 0.05339965224266052f;
+  p = p * a + 0.45877760648727417f;
+  p = p * a + 1.1512006521224976f;
+  p = p * a + 0.9999929666519165f;
+  e.x = __builtin_amdgcn_exp2f(-p.x);                         // raw v_exp_f32
+  e.y = __builtin_amdgcn_exp2f(-p.y);
+  r.x = fmaf(-a.x, e.x, fmaxf(v.x, 0.0f));
+  r.y = fmaf(-a.y, e.y, fmaxf(v.y, 0.0f));
   return r;
 }
 __device__ __forceinline__ float gelu_erf(float v) { return gelu_erf2(f2{v, v}).x; }

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "ftn_stage_times": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "ftn_debug_stamps": (C.c_int, [_P, C.c_size_t, C.c_int]),
     "ftn_selftest_mfma": (C.c_int, [_P, _P]),
+    "ftn_selftest_gelu": (C.c_int, [_P, _P, C.c_longlong, _P]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

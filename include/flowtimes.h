@@ -197,6 +197,8 @@ int ftn_debug_stamps(void* buf_dev, size_t n_u64, int which /* 1: k_conv, 2: k_m
 /* writes D = A(16x8, a[i][k]=i*8+k+1) * B(8x16, b[k][j]=(k+1)*100+j) via two
  * v_mfma_f32_16x16x4_f32 to out[16][16]: verifies the lane maps the kernels assume */
 int ftn_selftest_mfma(float* out_dev, void* stream);
+/* Diagnostic: out[i] = GELU(in[i]) exactly as the kernels evaluate nn.GELU() (erf form, :643). */
+int ftn_selftest_gelu(const float* in_dev, float* out_dev, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -535,3 +535,18 @@ def test_pipeline_shaped_call_hip_vs_cpu_mirror(ftn, dev):
     assert gpu.period_selector.last_selected_periods.tolist() == cpu.period_selector.last_selected_periods.tolist()
     np.testing.assert_allclose(rate.cpu().numpy(), want_r.numpy(), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(disp.cpu().numpy(), want_d.numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_gelu_accuracy(ftn, dev):
+    """The kernels' GELU (one v_exp_f32 + a degree-6 polynomial, ftn_common.h) against the erf form in fp64."""
+    lib = ftn.lib.load()
+    v = torch.cat([torch.linspace(-12, 12, 1_000_001), torch.tensor([0.0, -0.0, 1e-30, -1e-30, 50.0, -50.0, 3e4, -3e4])])
+    v = torch.cat([v, torch.zeros((-v.numel()) % 4)]).to(dev)
+    out = torch.empty_like(v)
+    ftn.lib.check(lib.ftn_selftest_gelu(v.data_ptr(), out.data_ptr(), v.numel(),
+                                        torch.cuda.current_stream().cuda_stream), "ftn_selftest_gelu")
+    want = torch.nn.functional.gelu(v.double().cpu())
+    err = (out.double().cpu() - want).abs()
+    assert float(err.max()) < 4e-7, float(err.max())
+    big = v.cpu().abs() > 12
+    assert float((out.cpu()[big] - torch.clamp(v.cpu()[big], min=0.0)).abs().max()) < 1e-13   # |v| clamps at 8
