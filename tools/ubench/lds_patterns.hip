@@ -55,5 +55,21 @@ int main() {
     snprintf(nm, sizeof nm, "  stride %d, (qa&1)*16, qa>>1 far apart", s);
     run(nm, o);
   }
+  // conv pattern (stride 112) with some lanes (taps outside the grid) redirected to a zero pixel
+  for (int nz : {1, 3, 6}) {
+    char nm[96];
+    for (int l = 0; l < 64; ++l) { const int j = l & 15, qa = l >> 4; const bool z = j < nz; o[l] = z ? 400 * 112 + (qa & 1) * 16 : (j + (qa >> 1)) * 112 + (qa & 1) * 16; }
+    snprintf(nm, sizeof nm, "conv pattern, %d of 16 pixels -> one shared zero pixel", nz);
+    run(nm, o);
+    for (int l = 0; l < 64; ++l) { const int j = l & 15, qa = l >> 4; const int np = j + (qa >> 1); const bool z = j < nz; o[l] = (z ? (400 | (np & 15)) : np) * 112 + (qa & 1) * 16; }
+    snprintf(nm, sizeof nm, "  same, zero pixels bank-matched (index & 15)");
+    run(nm, o);
+    for (int l = 0; l < 64; ++l) { const int j = l & 15, qa = l >> 4; const int np = j + (qa >> 1); const bool z = j < nz; o[l] = (z ? (400 | (np & 7)) : np) * 112 + (qa & 1) * 16; }
+    snprintf(nm, sizeof nm, "  same, zero pixels bank-matched (index & 7)");
+    run(nm, o);
+  }
+  // row wrap inside a unit: pixels 0..9 in one region row, 10..15 in the next (region 6 pixels wider than the tile)
+  for (int l = 0; l < 64; ++l) { const int j = l & 15, qa = l >> 4; const int np = j + (qa >> 1) + (j >= 10 ? 6 : 0); o[l] = np * 112 + (qa & 1) * 16; }
+  run("conv pattern with a row wrap (+6 pixels from lane 10)", o);
   return 0;
 }
