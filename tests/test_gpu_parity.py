@@ -550,3 +550,20 @@ def test_gelu_accuracy(ftn, dev):
     assert float(err.max()) < 4e-7, float(err.max())
     big = v.cpu().abs() > 12
     assert float((out.cpu()[big] - torch.clamp(v.cpu()[big], min=0.0)).abs().max()) < 1e-13   # |v| clamps at 8
+
+
+@pytest.mark.parametrize("K,L,C,hyper", [(12, 720, 64, "pipeline"), (16, 336, 32, "pipeline"), (16, 200, 16, "minimal")])
+def test_many_periods(K, L, C, hyper, ftn, dev):
+    """k_periods up to FTN_KMAX = 16: descriptor capacity, worst-case grids / workspace for many groups, and
+    duplicate periods collapsing into fewer groups (white-noise input: the candidates are whatever top-k finds)."""
+    case = dict(hyper=hyper, C=C, seed=31)
+    blk, P, ks, act = _block(ftn, case, dev)
+    blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(K, L)
+    x = torch.from_numpy(ftn.synth.make_input(3, L, C, seed=31, planted=(24, 7, 12, 50, 9, 33, 5, 16)))
+    y_ref, aux = orc.timesblock_forward(x, P, ks, act, K, L)
+    with torch.inference_mode():
+        y = blk(x.to(dev))
+    assert blk._last_backend == "hip"
+    assert blk.period_selector.last_selected_periods.tolist() == aux.sel.periods
+    assert blk._last_group_count == len(aux.groups.periods) and blk._last_raw_period_count == len(aux.sel.periods)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL)
