@@ -113,8 +113,17 @@ def load() -> C.CDLL:
         import subprocess
 
         if shutil.which("make") and (shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists()):
-            subprocess.run(["make", "-C", str(_HERE / "csrc"), "-j4"], check=False,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            import fcntl
+
+            # one builder at a time: the ranks of a multi-GPU launch all arrive here together
+            with open(_HERE / "csrc" / ".build.lock", "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if not path.exists():
+                        subprocess.run(["make", "-C", str(_HERE / "csrc"), "-j4"], check=False,
+                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
     if not path.exists():
         raise FlowTimesLibraryError(
             f"{path} not found: build it with `make -C {_HERE / 'csrc'}` "
