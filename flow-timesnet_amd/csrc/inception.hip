@@ -704,6 +704,149 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- stage C, bf16x3 engine, d_model 128
+// The same chain for the reference's default pipeline shape (configs/default.yaml: d_model 128, d_ff 512,
+// three kernels, ratio 4): nbr*mid = 96 = three K slabs of layer 1, d_model = 128 = four slabs of the
+// residual, 6 + 8 = 14 output tiles.  With two 16-pixel units per wave that needs ~340 registers, so a wave
+// owns ONE unit (oacc 56 + m pieces 36 + x pieces 48 registers) and the workgroup is 8 waves = 128 pixels;
+// the 28 fragments of a chunk (84 KB) live in a single LDS buffer.  A fragment then feeds 6 MFMAs instead of
+// 12 - which lands on the LDS read rate (tools/ubench/lds_patterns.hip) at about the time the SIMD needs
+// for MFMA + GELU anyway.  The chunk is walked as one unrolled fragment sequence with a one-ahead prefetch.
+template <int ACT, bool XVEC, int NS>
+__global__ __launch_bounds__(512, 2) void k_mlp_bf_c128(MlpBfArgs a) {
+  constexpr int SKM = 3, SCP = 4, OTM = 14, NFR = 2 * SKM + 2 * SCP + OTM;
+  extern __shared__ __attribute__((aligned(16))) char wlb[];
+  const FtnDesc* __restrict__ d = a.desc;
+  const int N = a.B * d->total_px;
+  if ((int)(blockIdx.x * 8 * 16) >= N) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int n0 = (blockIdx.x * 8 + wave) * 16;
+  const bool active = n0 < N;
+  const int bufsz = NFR * 3 * 1024;
+  auto dma_chunk = [&](int hc) {
+    const __bf16* __restrict__ src = a.cfrag + (size_t)hc * NFR * 3 * 512;
+    for (int piece = wv; piece < NFR * 3; piece += 8)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(wlb + (size_t)piece * 1024), 16, 0, 0);
+  };
+  const Px px = decode_px(d, a.x, a.B, a.L, a.C, n0 + j, N);
+  const int CP = a.CP;
+  const int kmg = a.KM >> 4;
+  bf8 mp[SKM][NS], xp[SCP][NS];
+  f4 xraw[SCP][2];
+#pragma unroll
+  for (int s = 0; s < SKM; ++s) {
+    const int grp = 2 * s + (qa >> 1);
+    const __bf16* __restrict__ src = a.m + ((size_t)px.n * kmg + (grp < kmg ? grp : 0)) * 48 + (qa & 1) * 8;
+#pragma unroll
+    for (int pz = 0; pz < NS; ++pz) mp[s][pz] = *(const bf8*)(src + pz * 16);
+  }
+#pragma unroll
+  for (int s = 0; s < SCP; ++s) {
+    xraw[s][0] = load_x4<XVEC>(px.xrow, 32 * s + 8 * qa, a.C);
+    xraw[s][1] = load_x4<XVEC>(px.xrow, 32 * s + 8 * qa + 4, a.C);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  dma_chunk(0);
+  const int FPc = a.n_hchunks * 32;
+  float* __restrict__ bias_l = (float*)(wlb + (size_t)bufsz);
+  for (int i = threadIdx.x; i < 2 * FPc; i += 512) {
+    const int c = i < FPc ? i : i - FPc;
+    bias_l[i] = c < a.FP ? (i < FPc ? a.bo[c] : a.br[c]) : 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < SKM; ++s) {
+    if (2 * s + (qa >> 1) >= kmg) {
+#pragma unroll
+      for (int pz = 0; pz < NS; ++pz)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mp[s][pz][e] = (__bf16)0.0f;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < SCP; ++s) {
+    float xv[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xv[e] = xraw[s][0][e]; xv[4 + e] = xraw[s][1][e]; }
+    split_pieces<NS>(xv, xp[s]);
+  }
+  f4 oacc[OTM];
+#pragma unroll
+  for (int o = 0; o < OTM; ++o) oacc[o] = *(const f4*)(a.bc + 16 * o + 4 * qa);
+  __syncthreads();
+  for (int hc = 0; hc < a.n_hchunks; ++hc) {
+    const char* __restrict__ wl = wlb + lane * 16;
+    f4 bo_t[2], br_t[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bo_t[t] = *(const f4*)(bias_l + 16 * (hc * 2 + t) + 4 * qa);
+      br_t[t] = *(const f4*)(bias_l + FPc + 16 * (hc * 2 + t) + 4 * qa);
+    }
+    if (active) {
+      f4 h[2] = {bo_t[0], bo_t[1]};
+      bf8 hp[NS];
+      bf8 fr[2][NS];
+      auto ldfrag = [&](int f, bf8 (&ap)[NS]) {
+#pragma unroll
+        for (int pz = 0; pz < NS; ++pz) ap[pz] = *(const bf8*)(wl + (size_t)(f * 3 + pz) * 1024);
+      };
+      ldfrag(0, fr[0]);
+#pragma unroll
+      for (int f = 0; f < NFR; ++f) {
+        if (f + 1 < NFR) ldfrag(f + 1, fr[(f + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf8 (&cur)[NS] = fr[f & 1];
+        if (f < SKM) h[0] = chain_bf<NS>(cur, mp[f], h[0]);                         // layer 1, hidden tile 0
+        else if (f < 2 * SKM) h[1] = chain_bf<NS>(cur, mp[f - SKM], h[1]);          // layer 1, hidden tile 1
+        else if (f < 2 * SKM + SCP) h[0] = chain_bf<NS>(cur, xp[f - 2 * SKM], h[0]);               // + res1(x)
+        else if (f < 2 * SKM + 2 * SCP) h[1] = chain_bf<NS>(cur, xp[f - 2 * SKM - SCP], h[1]);
+        else oacc[f - 2 * SKM - 2 * SCP] = chain_bf<NS>(cur, hp, oacc[f - 2 * SKM - 2 * SCP]);    // a' | res2
+        if (f == SKM - 1) h[0] = act4<ACT>(h[0]) + br_t[0];                          // act, then the residual adds on
+        if (f == 2 * SKM - 1) h[1] = act4<ACT>(h[1]) + br_t[1];
+        if (f == 2 * SKM + SCP - 1) h[0] = act4<ACT>(h[0]);                          // TimesBlock's mid activation
+        if (f == 2 * SKM + 2 * SCP - 1) {
+          h[1] = act4<ACT>(h[1]);
+          float hv[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hv[e] = h[0][e]; hv[4 + e] = h[1][e]; }
+          split_pieces<NS>(hv, hp);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    if (hc + 1 < a.n_hchunks) {
+      dma_chunk(hc + 1);
+      __syncthreads();
+    }
+  }
+  if (!active || !px.ok) return;
+#pragma unroll
+  for (int o = 0; o < OTM; ++o) {
+    if (o < a.n_oa) {
+      store_p3(a.outA + ((size_t)px.n * (a.AC >> 4) + o) * 48, qa, oacc[o]);
+    } else {
+      const int ch = 16 * (o - a.n_oa) + 4 * qa;
+      *(f4*)(a.outR + (size_t)px.n * CP + ch) = oacc[o] - load_x4<XVEC>(px.xrow, ch, a.C);
+    }
+  }
+}
+
+template <int ACT, int NS>
+static int launch_mlp_bf_c128(MlpBfArgs ma, bool xvec, long long Nmax, hipStream_t st) {
+  ma.dbg = nullptr; ma.dbg_cap = 0;
+  const size_t lds = (size_t)ma.per_chunk * 3 * 1024 + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
+  const int nblk = (int)((Nmax + 127) / 128);
+  hipError_t e = xvec ? hipFuncSetAttribute((const void*)k_mlp_bf_c128<ACT, true, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                      : hipFuncSetAttribute((const void*)k_mlp_bf_c128<ACT, false, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_bf_c128): %s", hipGetErrorString(e)); return (int)e; }
+  if (xvec) hipLaunchKernelGGL((k_mlp_bf_c128<ACT, true, NS>), dim3(nblk), dim3(512), lds, st, ma);
+  else hipLaunchKernelGGL((k_mlp_bf_c128<ACT, false, NS>), dim3(nblk), dim3(512), lds, st, ma);
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---------------------------------------------------------------- stages B / D
 // Grouped k x k convolution as an im2col GEMM.  One workgroup = one conv tile
 // (normally a whole period grid, <= 384 pixels) x one branch x NCO output-channel
@@ -1821,8 +1964,12 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     const int n_ot_c = CA / 16 + (pl->res2 ? CP / 16 : 0);
     const bool mlp_bf = use_bf && pl->cfragbf_per_chunk > 0 && pl->res1 && pl->res2 && CA > 32 && CA <= 64 && CP > 32 && CP <= 64 &&
                         n_ot_c <= 8 && (size_t)pl->cfragbf_per_chunk * 3 * 1024 * 2 <= 160 * 1024;
+    // the default pipeline shape (d_model 128, three kernels, mid 32): k_mlp_bf_c128
+    const bool mlp_bf128 = use_bf && !mlp_bf && pl->res1 && pl->res2 && CA == 96 && CP == 128 && n_ot_c == 14 &&
+                           pl->cfragbf_per_chunk == 28 &&
+                           (size_t)28 * 3 * 1024 + (size_t)pl->n_hchunks * 32 * 2 * sizeof(float) <= 160 * 1024;
     if (use_bf) {
-      cb.in = (const __bf16*)buf0; cb.out = buf1; cb.out_p3 = mlp_bf ? 1 : 0; cb.bias = wb + pl->b_conv1; cb.desc = desc;
+      cb.in = (const __bf16*)buf0; cb.out = buf1; cb.out_p3 = (mlp_bf || mlp_bf128) ? 1 : 0; cb.bias = wb + pl->b_conv1; cb.desc = desc;
       cb.B = B; cb.INC = CA; cb.OUTC = CA; cb.nbr = pl->nbr; cb.cin = pl->MP; cb.cout = pl->MP;
       cb.in_stride_br = pl->MP / 16; cb.out_stride_br = pl->MP;
       for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf1[k]); cb.kh[k] = pl->kh[k]; cb.kw[k] = pl->kw[k]; }
@@ -1847,7 +1994,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ma.outA_p3 = use_bf ? 1 : 0;
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model/mid too large for v1", ma.n_ot); return -1; }
     if (ma.cfrag_per_chunk != MLP_HT * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
-    if (mlp_bf) {
+    if (mlp_bf || mlp_bf128) {
       MlpBfArgs mb = {};
       mb.x = x; mb.m = (const __bf16*)buf1; mb.cfrag = (const __bf16*)(wb + pl->w_cfragbf);
       mb.bo = wb + pl->b_out1; mb.br = wb + pl->b_res1; mb.bc = wb + pl->b_c2;
@@ -1856,7 +2003,10 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
       mb.nsKM = (CA + 31) / 32; mb.nsCP = (CP + 31) / 32;
       mb.n_oa = CA / 16; mb.n_ot = n_ot_c; mb.n_hchunks = pl->n_hchunks; mb.per_chunk = pl->cfragbf_per_chunk;
       if (mb.per_chunk != 2 * mb.nsKM + 2 * mb.nsCP + mb.n_ot) { ftn_set_error("plan/cfragbf layout mismatch"); return -1; }
-      if (nsplit == 3) { if ((rc = launch_mlp_bf<ACT, 3>(mb, xvec, Nmax, st))) return rc; }
+      if (mlp_bf128) {
+        if (nsplit == 3) { if ((rc = launch_mlp_bf_c128<ACT, 3>(mb, xvec, Nmax, st))) return rc; }
+        else if ((rc = launch_mlp_bf_c128<ACT, 1>(mb, xvec, Nmax, st))) return rc;
+      } else if (nsplit == 3) { if ((rc = launch_mlp_bf<ACT, 3>(mb, xvec, Nmax, st))) return rc; }
       else if ((rc = launch_mlp_bf<ACT, 1>(mb, xvec, Nmax, st))) return rc;
     } else if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
     prof_mark(3, st);

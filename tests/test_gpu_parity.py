@@ -187,6 +187,7 @@ def test_block_matches_oracle_seeded(B, L, C, K, hyper, seed, engine, ftn, dev):
     (3, 400, 16, "pipeline", [64, 65, 399]),         # C=16: fp32 stage C beside the bf16 conv engine
     (2, 336, 64, "minimal", [24, 168]),              # single-conv mode (always the fp32 engine)
     (6, 1024, 64, "pipeline", [512, 16, 37]),        # long window
+    (3, 250, 128, "pipeline", [7, 249, 60]),         # d_model 128 (k_mlp_bf_c128): ragged last workgroup, pads
 ])
 def test_awkward_geometries_match_oracle(B, L, C, hyper, periods, engine, ftn, dev):
     case = dict(hyper=hyper, C=C, seed=21)
