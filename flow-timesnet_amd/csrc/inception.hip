@@ -1096,6 +1096,7 @@ struct ConvBfArgs {
   int region_bytes;      // one region buffer incl. the 96-byte zero pixel at its end
   int wbytes;            // weight fragment bytes in LDS
   int bpw;               // batch rows per workgroup
+  int sgroup;            // K=32 slabs whose weight fragments are resident at a time (>= max slabs: all of them)
   int kh[FTN_MAXBR], kw[FTN_MAXBR], order[FTN_MAXBR];
   unsigned long long* dbg; size_t dbg_cap;
 };
@@ -1167,19 +1168,22 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
             (__attribute__((address_space(3))) void*)(rbuf0 + (size_t)buf * a.region_bytes + (size_t)pc * 1024), 16, 0, 0);
       }
     };
-    auto dma_weights = [&](int cc) {
-      const int nfr = S * 3;                                  // 1-KiB fragments per output tile
+    // weight fragments of slabs [g0, g1) of channel chunk cc -> LDS slots [o][slab - g0][piece]
+    const int SG = a.sgroup < S ? a.sgroup : S;               // slabs resident at a time
+    auto dma_weights = [&](int cc, int g0, int g1) {
+      const int nfr = (g1 - g0) * 3;                          // 1-KiB fragments per output tile
       for (int o = 0; o < NCO; ++o) {
         if (co0 + o < nco_tot) {
-          const __bf16* __restrict__ src = a.W[br] + ((size_t)(cc * nco_tot + co0 + o) * nfr) * 512;
+          const __bf16* __restrict__ src = a.W[br] + ((size_t)(cc * nco_tot + co0 + o) * S + g0) * 3 * 512;
           for (int f = wv; f < nfr; f += 8)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 512 + lane * 8),
-                                             (__attribute__((address_space(3))) void*)(wl + ((size_t)o * nfr + f) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(wl + ((size_t)o * SG * 3 + f) * 1024), 16, 0, 0);
         } else {
-          for (int f = wv; f < nfr; f += 8) *(f4*)(wl + ((size_t)o * nfr + f) * 1024 + lane * 16) = f4{0.f, 0.f, 0.f, 0.f};
+          for (int f = wv; f < nfr; f += 8) *(f4*)(wl + ((size_t)o * SG * 3 + f) * 1024 + lane * 16) = f4{0.f, 0.f, 0.f, 0.f};
         }
       }
     };
+    const bool resident = ncc == 1 && SG == S;                // one staging per tile serves every batch row
 
     // per-lane pixel bookkeeping, once per tile (rotated by the workgroup's batch chunk so the
     // 3-unit waves spread over the SIMDs)
@@ -1205,7 +1209,7 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
       cmask[u] = pok[u] ? cm : 0u;
     }
     __syncthreads();                                          // previous tile's readers are done
-    if (ncc == 1) dma_weights(0);
+    if (resident) dma_weights(0, 0, S);
     if (b_begin < b_end) dma_region(b_begin, 0, 0);
     int it = 0;                                                // region buffer parity
     for (int b = b_begin; b < b_end; ++b) {
@@ -1218,7 +1222,7 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
         for (int u = 0; u < CBF_NU; ++u) acc[o][u] = bv;
       }
       for (int cc = 0; cc < ncc; ++cc) {
-        if (ncc > 1) { __syncthreads(); dma_weights(cc); }
+        if (!resident) { __syncthreads(); dma_weights(cc, 0, SG); }
         __syncthreads();                                      // region (b, cc) and weights have landed (vmcnt(0))
         if (b == b_begin && cc == 0) stamp(a.dbg, a.dbg_cap, wgid, 1);
         if (b == b_begin + 1 && cc == 0) stamp(a.dbg, a.dbg_cap, wgid, 2);
@@ -1235,7 +1239,7 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
         // the MFMAs of slab s (sched_barrier keeps hipcc from re-serialising them).
         int tl = qa >> 1;
         int dy = tl / kw, dx = tl - dy * kw;
-        int sload = 0;
+        int sload = 0, g0 = 0, g1 = SG;                       // resident slab group [g0, g1)
         auto load_slab = [&](bf8 (&bp)[CBF_NU][NS], bf8 (&ap)[NCO][NS]) {
           const bool tapok = tl < ntaps;
           const int toff = (dy * RW + dx) * P3_LDS_STRIDE;
@@ -1246,11 +1250,11 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
 #pragma unroll
             for (int pz = 0; pz < NS; ++pz) bp[u][pz] = *(const bf8*)(src + pz * 32);
           }
-          const int sa = sload < S ? sload : S - 1;
+          const int sa = (sload < g1 ? sload : g1 - 1) - g0;  // slot inside the resident group
 #pragma unroll
           for (int o = 0; o < NCO; ++o)
 #pragma unroll
-            for (int pz = 0; pz < NS; ++pz) ap[o][pz] = *(const bf8*)(wl + (((size_t)o * S + sa) * 3 + pz) * 1024 + lane * 16);
+            for (int pz = 0; pz < NS; ++pz) ap[o][pz] = *(const bf8*)(wl + (((size_t)o * SG + sa) * 3 + pz) * 1024 + lane * 16);
           ++sload; tl += 2; dx += 2;
           if (dx >= kw) { dx -= kw; ++dy; }
           if (dx >= kw) { dx -= kw; ++dy; }
@@ -1274,19 +1278,34 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
           }
         };
         bf8 bA[CBF_NU][NS], aA[NCO][NS], bB[CBF_NU][NS], aB[NCO][NS];
-        load_slab(bA, aA);
-        int sl = 0;
-        for (; sl + 2 <= S; sl += 2) {
-          load_slab(bB, aB);
-          __builtin_amdgcn_sched_barrier(0);
-          mma_slab(bA, aA);
-          __builtin_amdgcn_sched_barrier(0);
+        for (;;) {
+          const int ng = g1 - g0;
           load_slab(bA, aA);
-          __builtin_amdgcn_sched_barrier(0);
-          mma_slab(bB, aB);
-          __builtin_amdgcn_sched_barrier(0);
+          int sl = 0;
+          for (; sl + 2 <= ng; sl += 2) {
+            load_slab(bB, aB);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_slab(bA, aA);
+            __builtin_amdgcn_sched_barrier(0);
+            load_slab(bA, aA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_slab(bB, aB);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (sl < ng) mma_slab(bA, aA);
+          if (g1 >= S) break;
+          // next weight group: every wave is done with the resident fragments, then restage and rewind the
+          // tap walk to the group's first slab (the pipeline ran one or two slabs past it)
+          g0 = g1;
+          g1 = g0 + SG < S ? g0 + SG : S;
+          __syncthreads();
+          dma_weights(cc, g0, g1);
+          __syncthreads();
+          sload = g0;
+          tl = 2 * g0 + (qa >> 1);
+          dy = tl / kw;
+          dx = tl - dy * kw;
         }
-        if (sl < S) mma_slab(bA, aA);
       }
       // store this batch row's tile
       const size_t nimg = (size_t)a.B * d->g_px_off[g] + (size_t)b * P;
@@ -1796,11 +1815,11 @@ static int launch_conv(ConvArgs& ca, int B, int L, int grid_x, hipStream_t st) {
   return launch_conv_t<1>(ca, grid, lds, st);
 }
 
-struct ConvBfGeom { int NCO; size_t lds; int region_bytes, wbytes; };
+struct ConvBfGeom { int NCO; size_t lds; int region_bytes, wbytes, sgroup; };
 
 // LDS plan of the bf16x3 conv engine for window length L; NCO = 0 when it does not fit.
 static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int cout) {
-  ConvBfGeom gm = {0, 0, 0, 0};
+  ConvBfGeom gm = {0, 0, 0, 0, 0};
   int region_px = 1, smax = 1;
   for (int k = 0; k < nbr; ++k) {
     if (kh[k] > 31 || kw[k] > 31) return gm;
@@ -1811,10 +1830,18 @@ static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int
   }
   gm.region_bytes = ((region_px * P3_LDS_STRIDE + 1023) & ~1023) + P3_LDS_STRIDE;
   const int nco_tot = cout / 16;
+  // Output tiles per workgroup: more tiles share every pixel fragment read (the kernel is LDS-read bound).  When
+  // all slabs' weights do not fit beside the two region buffers, they are staged in groups of `sgroup` slabs.
   for (int nco = nco_tot >= 4 ? 4 : (nco_tot >= 2 ? 2 : 1); nco >= 1; nco >>= 1) {
-    size_t w = (size_t)nco * smax * 3 * 1024;
-    size_t tot = w + 2 * (size_t)gm.region_bytes;
-    if (tot <= 160 * 1024) { gm.NCO = nco; gm.lds = tot; gm.wbytes = (int)w; return gm; }
+    const size_t room = 160 * 1024 - 2 * (size_t)gm.region_bytes;
+    int sg = (int)(room / ((size_t)nco * 3 * 1024));
+    if (sg > smax) sg = smax;
+    if (sg >= smax || (sg >= 8 && nco > 1) || nco == 1) {
+      if (sg < 1) return gm;
+      const size_t w = (size_t)nco * sg * 3 * 1024;
+      gm.NCO = nco; gm.lds = w + 2 * (size_t)gm.region_bytes; gm.wbytes = (int)w; gm.sgroup = sg;
+      return gm;
+    }
   }
   return gm;
 }
@@ -1833,6 +1860,7 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
   ca.nchunk = ftn_cdiv(nco_tot, gm.NCO);
   ca.region_bytes = gm.region_bytes;
   ca.wbytes = gm.wbytes;
+  ca.sgroup = gm.sgroup;
   ca.dbg = (g_stamp_which & 1) ? g_stamp_buf : nullptr; ca.dbg_cap = g_stamp_cap;
   ca.bpw = 4;
   for (int k = 0; k < ca.nbr; ++k) ca.order[k] = k;
@@ -1948,7 +1976,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
   if (pl->mode == 0) {
     const int CA = pl->nbr * pl->MP;
     // conv engine: exact fp32 MFMA, or the bf16 matrix pipe (3 pieces = fp32-equivalent, 1 = plain bf16)
-    ConvBfGeom bfg = {0, 0, 0, 0};
+    ConvBfGeom bfg = {0, 0, 0, 0, 0};
     if (pl->engine != 0) bfg = conv_bf_geom(L, pl->nbr, pl->kh, pl->kw, pl->MP);
     const bool use_bf = pl->engine != 0 && bfg.NCO > 0;
     const int nsplit = pl->engine == 2 ? 1 : 3;
