@@ -1862,7 +1862,11 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
   ca.wbytes = gm.wbytes;
   ca.sgroup = gm.sgroup;
   ca.dbg = (g_stamp_which & 1) ? g_stamp_buf : nullptr; ca.dbg_cap = g_stamp_cap;
-  ca.bpw = 4;
+  // batch rows per (persistent) workgroup: as many as still leave ~2 workgroups per CU in the launch - each
+  // staging of a tile's weights and pixel bookkeeping is shared by the rows (8 rows: -3 % against 4 at B = 256)
+  ca.bpw = 1;
+  for (int bp = 8; bp > 1; bp >>= 1)
+    if ((long long)grid_x * ftn_cdiv(B, bp) * ca.nbr * ftn_cdiv(nco_tot, gm.NCO) >= 448) { ca.bpw = bp; break; }
   for (int k = 0; k < ca.nbr; ++k) ca.order[k] = k;
   for (int i = 1; i < ca.nbr; ++i) {
     int v = ca.order[i], jj = i - 1;
