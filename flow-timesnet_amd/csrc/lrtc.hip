@@ -91,11 +91,25 @@ __global__ __launch_bounds__(256) void k_lrtc(const float* __restrict__ coeff, c
   if (n0 >= N || l0 >= L) return;
   const float scale = *scale_p;
   float co[4][RT];
+  if (RT % 4 == 0 && R == RT && n0 + 3 < N) {
+    // the four series of this lane are 4*R contiguous floats: RT unguarded 16-byte loads in flight at once
+    // (the guarded scalar form below compiles to one load + branch + wait per coefficient, i.e. 4*RT
+    // serialised memory round trips at the head of every wave)
+    const f4* __restrict__ cp = (const f4*)(coeff + ((size_t)b * N + n0) * R);
+    f4 cv[RT];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < RT; ++i) cv[i] = cp[i];
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
-      co[k][r] = (n0 + k < N && r < R) ? scale * coeff[((size_t)b * N + n0 + k) * R + r] : 0.f;
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < RT; ++r) co[k][r] = scale * cv[(k * RT + r) >> 2][(k * RT + r) & 3];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+        co[k][r] = (n0 + k < N && r < R) ? scale * coeff[((size_t)b * N + n0 + k) * R + r] : 0.f;
+  }
   // mean over l of sum_r basis[l][r]*co[r] == sum_r cmean[r]*co[r]; cmean sits behind the basis
   const float* __restrict__ cmean = basis + (size_t)L * R;
   float mu[4] = {0.f, 0.f, 0.f, 0.f};
@@ -119,8 +133,8 @@ __global__ __launch_bounds__(256) void k_lrtc(const float* __restrict__ coeff, c
     const size_t o = ((size_t)b * L + l) * N + n0;
     if (VEC) {
       f4 v = {acc[0], acc[1], acc[2], acc[3]};
-      if (ADDX) v += *(const f4*)(x + o);
-      *(f4*)(out + o) = v;
+      if (ADDX) v += __builtin_nontemporal_load((const f4*)(x + o));
+      __builtin_nontemporal_store(v, (f4*)(out + o));                 // written once, never re-read here
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k)

@@ -49,12 +49,9 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
     const int o = t & 3, h = t >> 2, i = ln & 15, q = ln >> 4;
     const int n = n0 + 16 * o + i, k = 16 * S + 4 * q;
     f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n < a.N) {
-      const float* __restrict__ W = (h ? a.wsg : a.wmu) + (size_t)n * a.D + k;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (k + e < a.D) v[e] = W[e];
-    }
+    // D % 4 == 0 (checked by the entry point) and k % 4 == 0: the quad is all inside a row or all outside; one
+    // 16-byte load instead of four guarded scalar ones (which serialise into four memory round trips)
+    if (n < a.N && k < a.D) v = *(const f4*)((h ? a.wsg : a.wmu) + (size_t)n * a.D + k);
     wl[f] = v;
   }
   // per-series constants of the slice: [0] b_mu, [1] b_sigma, [2] dispersion floor
@@ -189,7 +186,8 @@ extern "C" int ftn_head_forward(const float* hidden_dev, long long rows, int S, 
   FTN_CHECK_ARG(rows >= 1 && S >= 1 && rows % S == 0 && N >= 1 && hist >= 1 && hist <= S,
                 "ftn_head_forward: rows=%lld S=%d N=%d hist=%d", rows, S, N, hist);
   FTN_CHECK_ARG(D >= 4 && D % 4 == 0 && D <= 128, "ftn_head_forward: d_model=%d must be a multiple of 4, <= 128", D);
-  FTN_CHECK_ARG(((uintptr_t)hidden_dev & 15) == 0, "ftn_head_forward: hidden must be 16-byte aligned");
+  FTN_CHECK_ARG((((uintptr_t)hidden_dev | (uintptr_t)w_mu_dev | (uintptr_t)w_sigma_dev) & 15) == 0,
+                "ftn_head_forward: hidden and the head weights must be 16-byte aligned");
   HeadArgs a;
   a.hidden = hidden_dev; a.wmu = w_mu_dev; a.bmu = b_mu_dev; a.wsg = w_sigma_dev; a.bsg = b_sigma_dev;
   a.tail = tail_dev; a.late = late_dev_or_null; a.floorv = floor_vec_dev_or_null;
