@@ -373,7 +373,10 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psu
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < FTN_KMAX; ++j) {
-      a[j] = (j < nsel) ? med[(size_t)b * F + sd.sel_freq[j]] : 0.f;
+      // unconditional load from a clamped index: a guarded load compiles to load + branch + wait per candidate
+      // (serialised memory round trips on this one-workgroup kernel's critical path)
+      const float mv = med[(size_t)b * F + (j < nsel ? sd.sel_freq[j] : 0)];
+      a[j] = (j < nsel) ? mv : 0.f;
       amps[(size_t)b * FTN_KMAX + j] = a[j];
       if (j < nsel && sd.sel_group[j] >= 0) mx = fmaxf(mx, a[j]);
     }
