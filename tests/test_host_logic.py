@@ -267,3 +267,21 @@ def test_full_model_mirror_cpu_matches_reference(name, manifest, golden, ftn):
     assert model.period_selector.last_selected_periods.tolist() == g["periods"].tolist()
     np.testing.assert_allclose(rate.numpy(), g["rate"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(disp.numpy(), g["dispersion"], rtol=1e-5, atol=1e-6)
+
+
+def test_missing_library_fails_loudly(ftn, monkeypatch, tmp_path):
+    """No fallback: when the shared library is absent the product raises (it never routes a ROCm tensor through
+    torch ops or the oracle).  Exercised with FLOWTIMES_LIB pointing at a file that does not exist."""
+    monkeypatch.setenv("FLOWTIMES_LIB", str(tmp_path / "absent" / "libflowtimes_hip.so"))
+    monkeypatch.setattr(ftn.lib, "_lib", None)
+    with pytest.raises(ftn.lib.FlowTimesLibraryError, match="no fallback"):
+        ftn.lib.load()
+    # a wrong ABI is refused as well
+    monkeypatch.delenv("FLOWTIMES_LIB")
+    monkeypatch.setattr(ftn.lib, "_lib", None)
+    monkeypatch.setattr(ftn.lib, "ABI_VERSION", ftn.lib.ABI_VERSION + 1)
+    with pytest.raises(ftn.lib.FlowTimesLibraryError, match="ABI version"):
+        ftn.lib.load()
+    monkeypatch.undo()
+    ftn.lib._lib = None
+    assert ftn.lib.load().ftn_abi_version() == ftn.lib.ABI_VERSION
