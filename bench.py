@@ -135,7 +135,7 @@ def main() -> None:
     alt_ms = {}
     if world == 1:
         # the other conv/chain arithmetic, timed briefly for comparison (same weights, same input)
-        for alt in ("f32", "bf16x3"):
+        for alt in ("f32", "bf16x3", "bf16"):    # "bf16" = BASELINE configs[2] (plain bf16 operands, fp32 accumulate)
             if alt == engine:
                 continue
             blk.engine = alt
