@@ -73,3 +73,30 @@ class ShardedTimesBlock(nn.Module):
         if gather == "async":
             return gather_batch(y, grp, async_op=True)
         return gather_batch(y, grp) if gather else y
+
+
+class ShardedTimesNet(nn.Module):
+    """Batch-sharded whole model (P2): the model's blocks share one ``FFTPeriodSelector``, so
+    pointing its ``shard_group`` at the process group makes every block exchange its ``[F]`` partial sums;
+    everything else in ``TimesNet.forward`` is row-wise or per-series and needs no communication.
+    ``forward`` returns this rank's ``(rate, dispersion)`` rows, or the all-gathered ones with ``gather=True``."""
+
+    def __init__(self, model: nn.Module, group=None) -> None:
+        super().__init__()
+        self.model = model
+        self.group = group
+        if not hasattr(model.period_selector, "shard_group"):
+            raise ValueError("ShardedTimesNet needs the mirror TimesNet (native FFTPeriodSelector)")
+
+    def forward(self, x_local: torch.Tensor, gather: bool = False, **kwargs):
+        sel = self.model.period_selector
+        grp = self.group if self.group is not None else dist.group.WORLD
+        prev = sel.shard_group
+        sel.shard_group = grp if (dist.get_world_size(grp) > 1 or os.environ.get("FTN_BENCH_FORCE_DIST") == "1") else None
+        try:
+            rate, disp = self.model(x_local, **kwargs)
+        finally:
+            sel.shard_group = prev
+        if gather:
+            return gather_batch(rate, grp), gather_batch(disp, grp)
+        return rate, disp

@@ -71,3 +71,65 @@ def test_batch_sharded_equals_single_process(name, tmp_path, golden):
     assert np.load(tmp_path / "p0.npy").tolist() == g["periods"].tolist()
     assert np.load(tmp_path / "p1.npy").tolist() == g["periods"].tolist()
     np.testing.assert_allclose(y0, g["y"], rtol=1e-4, atol=2e-5)
+
+
+def _fixture_model(pkg, name="m_context"):
+    man = json.loads((GOLDEN / "manifest.json").read_text())
+    cfg = dict(man["cases"][name]["cfg"])
+    cfg["kernel_set"] = [tuple(k) for k in cfg["kernel_set"]]
+    with np.load(GOLDEN / f"{name}.npz") as z:
+        g = {k: z[k] for k in z.files}
+    kw = {k: torch.from_numpy(g[k]) for k in ("series_static", "series_ids") if k in g}
+    x3 = torch.from_numpy(g["x"])
+    x = torch.cat([x3, torch.roll(x3[:1], 5, dims=1) * 0.7 + 0.3], dim=0)        # 4 rows: splits over 2 ranks
+    model = pkg.models.TimesNet(**cfg).eval()
+    with torch.no_grad():
+        model(x, **kw)
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    d_ff = cfg["d_ff"] if cfg.get("d_ff") else cfg["d_model"]
+    for li in range(cfg["n_layers"]):
+        prm = pkg.synth.make_inception_params(cfg["d_model"], d_ff, cfg["kernel_set"],
+                                              cfg.get("bottleneck_ratio", 1.0), seed=100 + li)
+        for k, v in prm.items():
+            sd[f"blocks.{li}.inception.{k}"] = torch.from_numpy(v)
+    model.load_state_dict(sd, strict=True)
+    return model, x, kw
+
+
+def _model_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, x, kw = _fixture_model(pkg)
+        runner = pkg.dist.ShardedTimesNet(model)
+        with torch.no_grad():
+            rate, disp = runner(x.chunk(world, dim=0)[rank], gather=True, **kw)
+            rate_l, _ = runner(x.chunk(world, dim=0)[rank], **kw)
+        assert model.period_selector.shard_group is None
+        assert torch.equal(rate.chunk(world, dim=0)[rank], rate_l)
+        np.save(os.path.join(out_dir, f"rate{rank}.npy"), rate.numpy())
+        np.save(os.path.join(out_dir, f"disp{rank}.npy"), disp.numpy())
+        np.save(os.path.join(out_dir, f"per{rank}.npy"), model.period_selector.last_selected_periods.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_sharded_model_equals_single_process(tmp_path, ftn):
+    """Whole model, batch split over two ranks: every block's selector sees the full-batch spectrum through the
+    partial-sum exchange, so the gathered outputs equal the single-process forward of the same mirror (which
+    tests/test_host_logic.py pins to the reference on this fixture's weights)."""
+    world = 2
+    model, x, kw = _fixture_model(ftn)
+    with torch.no_grad():
+        want_r, want_d = model(x, **kw)
+    want_p = model.period_selector.last_selected_periods.tolist()
+    mp.spawn(_model_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rate0.npy"), np.load(tmp_path / "rate1.npy")
+    assert np.array_equal(r0, r1)
+    assert np.load(tmp_path / "per0.npy").tolist() == want_p == np.load(tmp_path / "per1.npy").tolist()
+    np.testing.assert_allclose(r0, want_r.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.load(tmp_path / "disp0.npy"), want_d.numpy(), rtol=1e-5, atol=1e-6)
