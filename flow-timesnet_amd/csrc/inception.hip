@@ -1708,10 +1708,21 @@ extern "C" int ftn_stage_times(float* ms_sum, int nstage, int* ncalls) {
 }
 
 // ---------------------------------------------------------------- host side
-static int worst_px_per_row(int L, int max_groups) {
-  // P_g = L + pad <= 2L - 2; groups have distinct periods
-  long long w = (long long)max_groups * (2LL * L);
-  return (int)w;
+// Upper bound of FtnDesc.total_px (grid pixels per batch row): the caller's own bound when it has one
+// (ftn_selector_px_bound for the native selector, the descriptor's exact total_px for a host-built one),
+// otherwise the exact worst case over any `max_groups` distinct valid periods of a window of length L
+// (P_g = L + (-L mod p); periods just below L pad to almost 2L).
+static int worst_px_per_row(int L, int max_groups, int px_bound) {
+  if (px_bound > 0) return px_bound;
+  int best[FTN_KMAX] = {0};
+  for (int p = 1; p < L; ++p) {
+    int v = L + (p - (L % p)) % p;
+    for (int s = 0; s < max_groups; ++s)
+      if (v > best[s]) { int tmp = best[s]; best[s] = v; v = tmp; }
+  }
+  long long w = 0;
+  for (int s = 0; s < max_groups; ++s) w += best[s];
+  return w > 0 ? (int)w : L;
 }
 
 static void worst_tiles(int L, int max_groups, int* tiles_per_row) {
@@ -1753,14 +1764,16 @@ struct WsLayout {
   int c0, c1;  // channel counts of buf0 / buf1
 };
 
-static WsLayout ws_layout(const FtnPlan* pl, int B, int L, int max_groups) {
+#define FTN_WS_HEAD 1024   // sanitised copy of the descriptor (k_guard) at the head of the workspace
+
+static WsLayout ws_layout(const FtnPlan* pl, int B, int L, int max_groups, int px_bound) {
   WsLayout w;
-  const size_t N = (size_t)B * worst_px_per_row(L, max_groups);
+  const size_t N = (size_t)B * worst_px_per_row(L, max_groups, px_bound);
   const int CA = pl->nbr * pl->MP;
   w.c0 = pl->mode == 0 ? CA : pl->CP;                 // a / a'   (mode 1: padded x, then m')
   w.c1 = pl->mode == 0 ? CA : pl->FP;                 // m / m'   (mode 1: conv1 output)
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  w.off0 = 0;
+  w.off0 = FTN_WS_HEAD;
   w.off1 = al(w.off0 + N * w.c0 * (pl->engine != 0 && pl->mode == 0 ? 6 : 4));   // P3 = 6 bytes per value
   w.off2 = al(w.off1 + N * w.c1 * (pl->engine != 0 && pl->mode == 0 ? 6 : 4));   // R [N][CP]
   w.off3 = al(w.off2 + N * pl->CP * 4);               // G [N][FP] (mode 1)
@@ -1768,9 +1781,21 @@ static WsLayout ws_layout(const FtnPlan* pl, int B, int L, int max_groups) {
   return w;
 }
 
-extern "C" size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max_groups) {
-  if (!plan || B < 1 || L < 2 || max_groups < 1 || max_groups > FTN_KMAX) return 0;
-  return ws_layout(plan, B, L, max_groups).total;
+extern "C" size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max_groups, int px_bound) {
+  if (!plan || B < 1 || L < 2 || max_groups < 1 || max_groups > FTN_KMAX || px_bound < 0) return 0;
+  if ((long long)B * worst_px_per_row(L, max_groups, px_bound) > 0x7fffffffLL) return 0;   // flat pixel index is an int
+  return ws_layout(plan, B, L, max_groups, px_bound).total;
+}
+
+// Copies the caller's descriptor to the head of the workspace; a descriptor that exceeds the bounds the
+// workspace and the grids were sized for (more groups than max_groups, more pixels than px_bound) is
+// replaced by an empty one, which makes the call the identity y = x instead of a write past a buffer.
+__global__ void k_guard(const FtnDesc* __restrict__ src, FtnDesc* __restrict__ dst, int max_groups, int px_bound) {
+  const int* s = (const int*)src;
+  int* d = (int*)dst;
+  const bool bad = src->n_groups < 0 || src->n_groups > max_groups || src->total_px < 0 || src->total_px > px_bound;
+  for (int e = threadIdx.x; e < (int)(sizeof(FtnDesc) / 4); e += blockDim.x) d[e] = bad ? 0 : s[e];
+  if (threadIdx.x == 0) d[sizeof(FtnDesc) / 4] = bad ? 1 : 0;
 }
 
 template <int NCO>
@@ -1958,17 +1983,21 @@ static int launch_mlp_bf(const MlpBfArgs& ma, bool xvec, long long Nmax, hipStre
 }
 
 template <int ACT>
-static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, const float* wb, const FtnDesc* desc,
-                     const float* wts, int max_groups, char* ws, hipStream_t st, const float* ln_g, const float* ln_b,
-                     float ln_eps) {
-  const WsLayout wl = ws_layout(pl, B, L, max_groups);
+static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, const float* wb, const FtnDesc* desc_in,
+                     const float* wts, int max_groups, int px_bound, char* ws, hipStream_t st, const float* ln_g,
+                     const float* ln_b, float ln_eps) {
+  const WsLayout wl = ws_layout(pl, B, L, max_groups, px_bound);
+  const int px_row = worst_px_per_row(L, max_groups, px_bound);
+  hipLaunchKernelGGL(k_guard, dim3(1), dim3(256), 0, st, desc_in, (FtnDesc*)ws, max_groups, px_row);
+  FTN_CHECK_LAUNCH();
+  const FtnDesc* desc = (const FtnDesc*)ws;
   float* buf0 = (float*)(ws + wl.off0);
   float* buf1 = (float*)(ws + wl.off1);
   float* bufR = (float*)(ws + wl.off2);
   float* bufG = (float*)(ws + wl.off3);
   const int C = pl->C, CP = pl->CP, FP = pl->FP;
   const bool xvec = (C % 4 == 0) && (((uintptr_t)x & 15) == 0);
-  const long long Nmax = (long long)B * worst_px_per_row(L, max_groups);
+  const long long Nmax = (long long)B * px_row;
   int tiles_row;
   worst_tiles(L, max_groups, &tiles_row);
   const int nblk_pw = (int)((Nmax + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));
@@ -2117,7 +2146,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
 
 static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev, int max_groups,
-                           void* ws_dev, size_t ws_bytes, void* stream, const float* ln_g, const float* ln_b,
+                           int px_bound, void* ws_dev, size_t ws_bytes, void* stream, const float* ln_g, const float* ln_b,
                            float ln_eps) {
   FTN_CHECK_ARG(x_dev && y_dev && plan && wblob_dev && desc_dev && weights_dev && ws_dev,
                 "ftn_timesblock_forward: null pointer");
@@ -2129,31 +2158,34 @@ static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const
   FTN_CHECK_ARG(plan->mode == 1 || (plan->MP % 16 == 0 && plan->MP > 0), "ftn_timesblock_forward: bad MP");
   FTN_CHECK_ARG(plan->res1 || plan->CP == plan->FP, "identity res1 needs d_model == d_ff");
   FTN_CHECK_ARG(plan->res2 || plan->CP == plan->FP, "identity res2 needs d_model == d_ff");
-  const size_t need = ftn_timesblock_workspace_bytes(plan, B, L, max_groups);
+  FTN_CHECK_ARG(px_bound >= 0, "ftn_timesblock_forward: px_bound=%d", px_bound);
+  const size_t need = ftn_timesblock_workspace_bytes(plan, B, L, max_groups, px_bound);
+  FTN_CHECK_ARG(need > 0, "ftn_timesblock_forward: B*pixels per row exceeds 2^31 (B=%d L=%d)", B, L);
   FTN_CHECK_ARG(ws_bytes >= need, "ftn_timesblock_forward: workspace %zu < %zu bytes", ws_bytes, need);
   FTN_CHECK_ARG(((uintptr_t)ws_dev & 255) == 0 && ((uintptr_t)wblob_dev & 15) == 0,
                 "ftn_timesblock_forward: workspace/weights must be 256/16-byte aligned");
   if (plan->act == 1)
-    return forward_t<1>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, (char*)ws_dev,
+    return forward_t<1>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, (char*)ws_dev,
                         (hipStream_t)stream, ln_g, ln_b, ln_eps);
-  return forward_t<0>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, (char*)ws_dev,
+  return forward_t<0>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, (char*)ws_dev,
                       (hipStream_t)stream, ln_g, ln_b, ln_eps);
 }
 
 extern "C" int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                       const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                                      int max_groups, void* ws_dev, size_t ws_bytes, void* stream) {
-  return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, ws_dev, ws_bytes,
+                                      int max_groups, int px_bound, void* ws_dev, size_t ws_bytes, void* stream) {
+  return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, ws_dev, ws_bytes,
                          stream, nullptr, nullptr, 0.f);
 }
 
 extern "C" int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                                           int max_groups, const float* ln_gamma_dev, const float* ln_beta_dev,
-                                           float ln_eps, void* ws_dev, size_t ws_bytes, void* stream) {
+                                           int max_groups, int px_bound, const float* ln_gamma_dev,
+                                           const float* ln_beta_dev, float ln_eps, void* ws_dev, size_t ws_bytes,
+                                           void* stream) {
   FTN_CHECK_ARG(ln_gamma_dev && ln_beta_dev && ln_eps >= 0.f, "ftn_timesblock_forward_norm: LayerNorm parameters");
-  return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, ws_dev, ws_bytes,
-                         stream, ln_gamma_dev, ln_beta_dev, ln_eps);
+  return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, ws_dev,
+                         ws_bytes, stream, ln_gamma_dev, ln_beta_dev, ln_eps);
 }
 
 extern "C" int ftn_residual_layernorm(const float* x_dev, const float* new_dev, float* out_dev, long long rows, int C,

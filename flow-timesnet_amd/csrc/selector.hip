@@ -421,6 +421,39 @@ extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btota
   return 0;
 }
 
+// Bound on FtnDesc.total_px / n_groups for descriptors written by ftn_period_finalize: the selector can only
+// produce periods clamp(ceil(L/i), lo, hi) for rFFT bins i = 1..F-1 (:144-145), at most k of them, so the
+// sum of the k largest L + pad over those distinct periods bounds the grid pixels per batch row.  For
+// i >= 2 the pad is < i, i.e. (almost) every group is L pixels plus a few; only bin 1 (period L-1) doubles.
+extern "C" int ftn_selector_px_bound(int L, int k_periods, int pmax, int min_period_threshold, int* max_groups_out) {
+  FTN_CHECK_ARG(L >= 2 && k_periods <= FTN_KMAX, "ftn_selector_px_bound: L=%d k=%d", L, k_periods);
+  if (k_periods < 0) k_periods = 0;
+  if (pmax < 1) pmax = 1;
+  if (min_period_threshold < 1) min_period_threshold = 1;
+  if (min_period_threshold > pmax) min_period_threshold = pmax;
+  const int F = L / 2 + 1;
+  const int k = k_periods < F - 1 ? k_periods : F - 1;
+  const int hi = pmax < (L - 1 > 1 ? L - 1 : 1) ? pmax : (L - 1 > 1 ? L - 1 : 1), lo = min_period_threshold;
+  int best[FTN_KMAX] = {0};
+  int ndist = 0, last = -1;
+  if (hi >= lo) {
+    for (int i = 1; i < F; ++i) {                 // periods are non-increasing in i: distinct values are runs
+      int p = (L + i - 1) / i;
+      p = p < lo ? lo : (p > hi ? hi : p);
+      if ((L + p - 1) / p < 2 || p == last) continue;
+      last = p;
+      ++ndist;
+      int v = L + (p - (L % p)) % p;
+      for (int s = 0; s < k; ++s)
+        if (v > best[s]) { int tmp = best[s]; best[s] = v; v = tmp; }
+    }
+  }
+  long long sum = 0;
+  for (int s = 0; s < k; ++s) sum += best[s];
+  if (max_groups_out) *max_groups_out = ndist < k ? (ndist > 0 ? ndist : 1) : (k > 0 ? k : 1);
+  return sum > 0 ? (int)sum : L;
+}
+
 extern "C" int ftn_desc_from_periods(const int64_t* periods, int K, int L, int min_period, int max_period,
                                      FtnDesc* d) {
   FTN_CHECK_ARG(periods && d && K >= 0 && K <= FTN_KMAX && L >= 1, "ftn_desc_from_periods: bad argument (K=%d)", K);

@@ -35,7 +35,7 @@ def gather_batch(y_local: torch.Tensor, group=None, async_op: bool = False):
         return (y_local, None) if async_op else y_local
     y_local = y_local.contiguous()
     out = y_local.new_empty((world * y_local.shape[0],) + tuple(y_local.shape[1:]))
-    if y_local.is_cuda:
+    if y_local.is_cuda and dist.get_backend(group) != "gloo":
         work = dist.all_gather_into_tensor(out, y_local, group=group, async_op=async_op)
     else:  # gloo (CPU tests)
         parts = list(out.chunk(world, dim=0))

@@ -13,7 +13,7 @@ from typing import Optional
 
 FTN_KMAX = 16
 FTN_MAXBR = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libflowtimes_hip.so"
@@ -76,11 +76,12 @@ _SIGNATURES = {
                                       _P, _P, _P, _P]),
     "ftn_desc_from_periods": (C.c_int, [C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(FtnDesc)]),
-    "ftn_timesblock_workspace_bytes": (C.c_size_t, [C.POINTER(FtnPlan), C.c_int, C.c_int, C.c_int]),
-    "ftn_timesblock_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FtnPlan), _P, _P, _P, C.c_int,
+    "ftn_selector_px_bound": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "ftn_timesblock_workspace_bytes": (C.c_size_t, [C.POINTER(FtnPlan), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ftn_timesblock_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FtnPlan), _P, _P, _P, C.c_int, C.c_int,
                                          _P, C.c_size_t, _P]),
     "ftn_timesblock_forward_norm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FtnPlan), _P, _P, _P, C.c_int,
-                                              _P, _P, C.c_float, _P, C.c_size_t, _P]),
+                                              C.c_int, _P, _P, C.c_float, _P, C.c_size_t, _P]),
     "ftn_residual_layernorm": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int, _P, _P, C.c_float, _P]),
     "ftn_head_forward": (C.c_int, [_P, C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_longlong,
                                    C.c_int, _P, C.c_longlong, _P, C.c_float, _P, _P, _P, _P]),
@@ -106,24 +107,31 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = Path(os.environ.get("FLOWTIMES_LIB", LIB_PATH))
-    if not path.exists() and "FLOWTIMES_LIB" not in os.environ:
-        # in-tree build on first use (hipcc cross-compiles gfx950 without a GPU); a failed
-        # build is an error, never a fallback
+    build_log = ""
+    if "FLOWTIMES_LIB" not in os.environ:
+        # In-tree build on every first use (hipcc cross-compiles gfx950 without a GPU): `make` is a no-op when
+        # the library is newer than its sources and rebuilds it when it is not, so a stale .so (it is git-ignored
+        # but travels with the tree) can never be what the tests validate.  A failed build is an error with the
+        # compiler's output attached, never a fallback.
         import shutil
         import subprocess
 
-        if shutil.which("make") and (shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists()):
+        hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if Path("/opt/rocm/bin/hipcc").exists() else None)
+        if shutil.which("make") and hipcc:
             import fcntl
 
             # one builder at a time: the ranks of a multi-GPU launch all arrive here together
             with open(_HERE / "csrc" / ".build.lock", "w") as lock:
                 fcntl.flock(lock, fcntl.LOCK_EX)
                 try:
-                    if not path.exists():
-                        subprocess.run(["make", "-C", str(_HERE / "csrc"), "-j4"], check=False,
-                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    proc = subprocess.run(["make", "-C", str(_HERE / "csrc"), "-j4"], check=False,
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                    if proc.returncode != 0:
+                        build_log = proc.stdout[-4000:]
                 finally:
                     fcntl.flock(lock, fcntl.LOCK_UN)
+            if build_log:
+                raise FlowTimesLibraryError(f"building {path} failed; there is no fallback path:\n{build_log}")
     if not path.exists():
         raise FlowTimesLibraryError(
             f"{path} not found: build it with `make -C {_HERE / 'csrc'}` "

@@ -40,8 +40,18 @@ def _env_on(name: str) -> bool:
     return bool(v) and v.strip().lower() not in {"0", "false", "off"}
 
 
-def _hip_eligible(x: torch.Tensor) -> bool:
-    return x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad)
+def _hip_eligible(x: torch.Tensor, *modules) -> bool:
+    """The HIP kernels are forward-only: they run when the input lives on a ROCm device and autograd has
+    nothing to record - grad mode off, or neither the input nor any parameter of ``modules`` requires
+    grad.  (A frozen input in front of trainable blocks must still take the torch path, or the block
+    weights would silently receive no gradient.)"""
+    if not x.is_cuda:
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    if x.requires_grad:
+        return False
+    return not any(p.requires_grad for m in modules if m is not None for p in m.parameters())
 
 
 # =========================================================================
@@ -125,7 +135,10 @@ class FFTPeriodSelector(nn.Module):
 
             world = dist.get_world_size(self.shard_group)
             parts = torch.empty(world, psum.numel(), dtype=psum.dtype, device=psum.device)
-            dist.all_gather_into_tensor(parts, psum, group=self.shard_group)
+            if dist.get_backend(self.shard_group) == "gloo":      # CPU-side rehearsal of the exchange
+                dist.all_gather(list(parts.unbind(0)), psum, group=self.shard_group)
+            else:                                                  # RCCL
+                dist.all_gather_into_tensor(parts, psum, group=self.shard_group)
             b_total = B * world          # equal shards (no host sync to learn otherwise)
             psum = parts
         sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold)
@@ -362,9 +375,10 @@ class TimesBlock(nn.Module):
             if self.d_model is not None and x.size(-1) != self.d_model:
                 raise ValueError("Number of channels changed between calls")
 
-        use_hip = (_hip_eligible(x) and self._standard_inception()
-                   and not (self.training and self._dropout > 0.0))
-        fused = post_norm is not None and use_hip and _affine_layernorm(post_norm, x.size(-1))
+        use_hip = (self._standard_inception() and not (self.training and self._dropout > 0.0)
+                   and _hip_eligible(x, self.inception))
+        fused = (post_norm is not None and use_hip and _affine_layernorm(post_norm, x.size(-1))
+                 and _hip_eligible(x, post_norm))
         if not use_hip:
             self._last_backend = "torch"
             new = self._forward_torch(x)

@@ -1,6 +1,7 @@
 """Per-device HIP runtime state for the TimesBlock path: DFT twiddle tables,
-LRTC bases, a grow-only workspace, and the thin call wrappers that pass
-``tensor.data_ptr()`` / the current HIP stream into the C ABI.
+LRTC bases, and the thin call wrappers that pass ``tensor.data_ptr()`` / the
+current HIP stream into the C ABI.  Workspaces are allocated per call from
+torch's caching allocator (stream- and graph-pool-safe; free after warm-up).
 
 PyTorch is plumbing here (device memory + streams); every computation happens
 in ``libflowtimes_hip.so``.
@@ -31,7 +32,6 @@ class DeviceState:
         self.device = device
         self.tables: Dict[int, torch.Tensor] = {}
         self.bases: Dict[Tuple[int, int], torch.Tensor] = {}
-        self.workspace = torch.empty(0, dtype=torch.uint8, device=device)
 
     def dft_table(self, L: int) -> torch.Tensor:
         t = self.tables.get(L)
@@ -53,12 +53,6 @@ class DeviceState:
             self.bases[key] = t
         return t
 
-    def get_workspace(self, nbytes: int) -> torch.Tensor:
-        if self.workspace.numel() < nbytes:
-            self.workspace = torch.empty(0, dtype=torch.uint8, device=self.device)  # drop the old block first
-            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self.workspace
-
 
 _states: Dict[int, DeviceState] = {}
 
@@ -76,11 +70,13 @@ def state(device: torch.device) -> DeviceState:
 class Selection:
     """Device-resident result of the period selector for one block call."""
 
-    def __init__(self, desc: torch.Tensor, amps: torch.Tensor, weights: torch.Tensor, max_groups: int) -> None:
+    def __init__(self, desc: torch.Tensor, amps: torch.Tensor, weights: torch.Tensor, max_groups: int,
+                 px_bound: int = 0) -> None:
         self.desc = desc          # int32 [DESC_INTS]
         self.amps = amps          # [B, FTN_KMAX]
         self.weights = weights    # [B, FTN_KMAX]
-        self.max_groups = max_groups
+        self.max_groups = max_groups     # >= desc.n_groups
+        self.px_bound = px_bound         # >= desc.total_px (0: generic worst case)
         self._host = None
 
     def host(self) -> FtnDesc:
@@ -117,7 +113,11 @@ def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int
     check(lib.ftn_period_finalize(_ptr(psum), nparts, int(b_total), _ptr(med), B, L, int(k), int(pmax),
                                   int(min_thr), _ptr(desc), _ptr(amps), _ptr(wts), _stream(dev)),
           "ftn_period_finalize")
-    return Selection(desc, amps, wts, max(1, min(int(k), FTN_KMAX)))
+    mg = C.c_int(0)
+    pxb = lib.ftn_selector_px_bound(L, int(k), int(pmax), int(min_thr), C.byref(mg))
+    if pxb < 0:
+        check(pxb, "ftn_selector_px_bound")
+    return Selection(desc, amps, wts, max(1, int(mg.value)), int(pxb))
 
 
 def selection_from_host(desc_host: FtnDesc, weights: torch.Tensor, device: torch.device) -> Selection:
@@ -129,7 +129,7 @@ def selection_from_host(desc_host: FtnDesc, weights: torch.Tensor, device: torch
     B, G = weights.shape
     w = torch.zeros(B, FTN_KMAX, dtype=torch.float32, device=device)
     w[:, :G] = weights.to(device=device, dtype=torch.float32)
-    sel = Selection(desc, w, w, max(1, int(desc_host.n_groups)))
+    sel = Selection(desc, w, w, max(1, int(desc_host.n_groups)), max(1, int(desc_host.total_px)))
     sel._host = desc_host
     return sel
 
@@ -141,21 +141,23 @@ def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel:
     (reference :2050-2058) to the same call."""
     lib = _lib.load()
     B, L, _ = x.shape
-    st = state(x.device)
-    need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, sel.max_groups)
+    need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, sel.max_groups, sel.px_bound)
     if need == 0:
-        raise ValueError("ftn_timesblock_workspace_bytes rejected the shape")
-    ws = st.get_workspace(need)
+        raise ValueError(f"ftn_timesblock_workspace_bytes rejected the shape (B={B}, L={L})")
+    # one workspace per call, from the caching allocator: ordered on the calling stream, private to a graph
+    # capture's pool, never shared between calls in flight (a process-wide buffer would be)
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     y = torch.empty_like(x)
     if norm is not None:
         g, b, eps = norm
         check(lib.ftn_timesblock_forward_norm(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
-                                              _ptr(sel.weights), sel.max_groups, _ptr(g), _ptr(b), float(eps),
+                                              _ptr(sel.weights), sel.max_groups, sel.px_bound, _ptr(g), _ptr(b),
+                                              float(eps),
                                               _ptr(ws), ws.numel(), _stream(x.device)),
               "ftn_timesblock_forward_norm")
         return y
     check(lib.ftn_timesblock_forward(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
-                                     _ptr(sel.weights), sel.max_groups, _ptr(ws), ws.numel(),
+                                     _ptr(sel.weights), sel.max_groups, sel.px_bound, _ptr(ws), ws.numel(),
                                      _stream(x.device)), "ftn_timesblock_forward")
     return y
 

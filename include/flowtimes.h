@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTN_ABI_VERSION 5
+#define FTN_ABI_VERSION 6
 #define FTN_KMAX 16      /* max period candidates / groups per block call        */
 #define FTN_MAXBR 8      /* max kernels in kernel_set                             */
 
@@ -122,20 +122,32 @@ int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const fl
 int ftn_desc_from_periods(const int64_t* periods, int K, int L, int min_period, int max_period,
                           FtnDesc* desc_host);
 
+/* Host-only: upper bounds for descriptors that ftn_period_finalize can write for this selector
+ * configuration: returns the bound on total_px (grid pixels per batch row, > 0; < 0 on a bad argument)
+ * and stores the bound on n_groups.  The selector only emits periods clamp(ceil(L/i), lo, hi) for rFFT
+ * bins i (:144-145), whose pads are tiny except for bin 1, so this is far below the generic worst case. */
+int ftn_selector_px_bound(int L, int k_periods, int pmax, int min_period_threshold, int* max_groups_out);
+
 /* ---- TimesBlock conv path: _period_conv_bucketed_slicing (:955-1101) --------- */
-size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max_groups);
+/* Workspace / grids are sized from bounds on the device-side descriptor: max_groups >= desc->n_groups and
+ * px_bound >= desc->total_px (ftn_selector_px_bound, or the exact total_px of a host-built descriptor;
+ * 0 = the worst case over any max_groups distinct periods, almost 2*L*max_groups).  A descriptor that
+ * exceeds them makes the call the identity y = x; nothing is ever written past the workspace.  The
+ * workspace belongs to ONE call in flight: calls that may overlap (different streams, or a captured
+ * graph beside eager calls) need their own.  Returns 0 for a shape it cannot run. */
+size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max_groups, int px_bound);
 /* y = x + sum_g w[b,g] * (inception(fold_g(x)) - fold_g(x))[:L]  (:1041-1092, :818).
- * desc/weights are device pointers; max_groups bounds desc->n_groups (grid sizing). */
+ * desc/weights are device pointers. */
 int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                           int max_groups, void* ws_dev, size_t ws_bytes, void* stream);
+                           int max_groups, int px_bound, void* ws_dev, size_t ws_bytes, void* stream);
 /* The same call followed by the caller's per-block epilogue of TimesNet.forward (:2050-2058, eval mode):
  *   y = LayerNorm_C( x + (block(x) - x) ; gamma, beta, eps )
  * fused into the last kernel when d_model <= 64 (bottleneck mode), one extra in-place row pass otherwise. */
 int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                 const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                                int max_groups, const float* ln_gamma_dev, const float* ln_beta_dev, float ln_eps,
-                                void* ws_dev, size_t ws_bytes, void* stream);
+                                int max_groups, int px_bound, const float* ln_gamma_dev, const float* ln_beta_dev,
+                                float ln_eps, void* ws_dev, size_t ws_bytes, void* stream);
 /* out[row][:] = LayerNorm_C( x[row][:] + (new[row][:] - x[row][:]) ) for rows x C fp32 matrices (in place
  * allowed: out == new).  Used when a block returns x unchanged (no valid period, :796-797). */
 int ftn_residual_layernorm(const float* x_dev, const float* new_dev, float* out_dev, long long rows, int C,

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(ftn):
     assert declared == set(ftn.lib.EXPORTS), declared ^ set(ftn.lib.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ftn_abi_version() == ftn.lib.ABI_VERSION == 5
+    assert lib.ftn_abi_version() == ftn.lib.ABI_VERSION == int(re.search(r"FTN_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_struct_sizes_match_header(ftn):
@@ -285,3 +285,33 @@ def test_missing_library_fails_loudly(ftn, monkeypatch, tmp_path):
     monkeypatch.undo()
     ftn.lib._lib = None
     assert ftn.lib.load().ftn_abi_version() == ftn.lib.ABI_VERSION
+
+
+@pytest.mark.parametrize("L,k,pmax,thr", [(336, 5, 336, 1), (720, 5, 720, 1), (96, 2, 96, 1), (97, 16, 97, 1),
+                                          (336, 5, 100, 7), (48, 3, 10, 4), (25, 4, 25, 1), (2, 3, 2, 1)])
+def test_selector_px_bound_covers_every_selectable_descriptor(ftn, L, k, pmax, thr):
+    """ftn_selector_px_bound must dominate total_px / n_groups of ANY k bins the selector could pick
+    (periods clamp(ceil(L/i), lo, hi), reference :144-148) and be attained by the worst choice."""
+    lib = ftn.lib.load()
+    mg = ctypes.c_int(0)
+    bound = lib.ftn_selector_px_bound(L, k, pmax, thr, ctypes.byref(mg))
+    assert bound > 0 and 1 <= mg.value <= ftn.lib.FTN_KMAX
+    F = L // 2 + 1
+    kk = min(k, F - 1)
+    hi, lo = min(pmax, max(1, L - 1)), min(pmax, max(1, thr))
+    per = {}
+    for i in range(1, F):
+        p = min(max((L + i - 1) // i, lo), hi)
+        if hi >= lo and (L + p - 1) // p >= 2:
+            per.setdefault(p, i)
+    worst = sorted((L + (-L) % p for p in per), reverse=True)[:kk]
+    assert bound == (sum(worst) if worst else L)
+    assert mg.value == max(1, min(kk, len(per)))
+    rs = np.random.RandomState(L + k)
+    bins = list(range(1, F))
+    for _ in range(50):
+        pick = rs.choice(bins, size=min(kk, len(bins)), replace=False) if bins and kk else []
+        periods = [min(max((L + i - 1) // i, lo), hi) for i in pick]
+        periods = [p for p in periods if hi >= lo and (L + p - 1) // p >= 2]
+        d = ftn.lib.desc_from_periods(periods, L, lo, pmax)
+        assert d.total_px <= bound and d.n_groups <= mg.value
