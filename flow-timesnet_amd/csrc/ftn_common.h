@@ -108,6 +108,8 @@ __host__ __device__ inline void ftn_build_groups(const int* periods, int K, int 
     d->g_tw[g] = 0; d->g_th[g] = 0; d->g_ntx[g] = 0; d->g_nty[g] = 0;
     if (g > G) { d->g_px_off[g] = px; d->g_tile_off[g] = tiles; }
   }
+  d->g_px_off[FTN_KMAX] = px;          // every word of the descriptor is defined (it is compared / hashed bytewise)
+  d->g_tile_off[FTN_KMAX] = tiles;
   for (int j = 0; j < K; ++j) {
     int p = periods[j];
     if (p <= 0 || p < min_period || p > max_period) continue;

@@ -104,14 +104,27 @@ __device__ __forceinline__ f4 load_x4(const float* __restrict__ xrow, int c, int
 // R   = act(W.in + b) + R     (EPI 1, in place)
 template <int ACT, bool XIN, bool XVEC, int EPI>
 __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
+  // XIN (stage A): a = W_in1 x + b depends on (b, t) only, not on the period group, so it is computed once per
+  // window position - rows n = b*L + t of `out` - plus ONE pad row n = B*L for the live zero pixels t >= L of
+  // every grid (x = 0 there, :1017, so a = bias).  The conv stage folds these rows into its period grids while
+  // staging (ConvArgs.bt_L), which is the reference's reshape (:1041-1046) done by index arithmetic.
   const FtnDesc* __restrict__ d = a.desc;
-  const int N = a.B * d->total_px;
+  const int N = XIN ? a.B * a.L + 1 : a.B * d->total_px;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int n0 = (blockIdx.x * 4 + wave) * (16 * NPXU);
   if (n0 >= N) return;
   Px px[NPXU];
 #pragma unroll
-  for (int u = 0; u < NPXU; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
+  for (int u = 0; u < NPXU; ++u) {
+    if (XIN) {
+      const int n = n0 + 16 * u + j;
+      px[u].ok = n < N;
+      px[u].n = px[u].ok ? n : N - 1;
+      px[u].xrow = px[u].n < N - 1 ? a.x + (size_t)px[u].n * a.C : nullptr;
+    } else {
+      px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
+    }
+  }
   const int KIN = a.KIN;
   for (int og = 0; og < a.n_ot; og += 4) {
     f4 acc[4][NPXU];
@@ -873,6 +886,9 @@ struct ConvArgs {
   int region_floats;     // LDS floats reserved for the staged region (+ zero slot)
   int kh[FTN_MAXBR], kw[FTN_MAXBR];
   int order[FTN_MAXBR];  // branches sorted by descending tap count (heavy workgroups first)
+  int bt_L;              // > 0: `in` holds one row per window position, [B*L + 1][INC] (row B*L = the zero-input
+                         // pad pixel), shared by every period group; grid pixel t of batch row b is row
+                         // b*L + t for t < L and the pad row otherwise.  0: `in` is per grid pixel, [N][INC]
   unsigned long long* dbg; size_t dbg_cap;
 };
 
@@ -966,7 +982,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   float* __restrict__ wl = lds + a.region_floats;
   const int zoff = a.region_floats - 16;                 // 16 zero floats at the end of the region area
   const size_t nimg = (size_t)a.B * d->g_px_off[g] + (size_t)b * P;
-  const float* __restrict__ in = a.in + nimg * a.INC + br * a.in_stride_br;
+  const int btL = a.bt_L;
+  const float* __restrict__ in = a.in + (btL > 0 ? (size_t)b * btL : nimg) * a.INC + br * a.in_stride_br;
+  const float* __restrict__ in_pad = a.in + (size_t)a.B * btL * a.INC + br * a.in_stride_br;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int npx = th * tw, nunits = (npx + 15) >> 4;
   const int wrot = (wave + b) & 3;                                 // rotate so co-resident workgroups balance the SIMDs
@@ -1035,8 +1053,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         const int s = s0 + 256 * k;
         const int sp = s >> 2, qq = s & 3;
         const int rr = (int)(((float)sp + 0.5f) * inv_rw), cx = sp - rr * RW;
-        v[k] = s < nstage ? *(const f4*)(in + (size_t)((R0 + rr) * p + C0 + cx) * a.INC + 16 * cc + 4 * qq)
-                          : f4{0.f, 0.f, 0.f, 0.f};
+        const int tpx = (R0 + rr) * p + C0 + cx;               // grid pixel = window position t (fold, :1041-1046)
+        const float* __restrict__ row = (btL > 0 && tpx >= btL) ? in_pad : in + (size_t)tpx * a.INC;
+        v[k] = s < nstage ? *(const f4*)(row + 16 * cc + 4 * qq) : f4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
@@ -1098,6 +1117,7 @@ struct ConvBfArgs {
   int bpw;               // batch rows per workgroup
   int sgroup;            // K=32 slabs whose weight fragments are resident at a time (>= max slabs: all of them)
   int kh[FTN_MAXBR], kw[FTN_MAXBR], order[FTN_MAXBR];
+  int bt_L;              // as ConvArgs.bt_L: > 0 = input rows per window position + one pad row
   unsigned long long* dbg; size_t dbg_cap;
 };
 
@@ -1153,9 +1173,11 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
     const int npieces = (nchunks16 + 63) >> 6;             // 1-KiB DMA instructions
 
     // region of batch row b, channel group cc -> buffer `buf`
+    const int btL = a.bt_L;
     auto dma_region = [&](int b, int cc, int buf) {
-      const __bf16* __restrict__ src = a.in + ((size_t)a.B * d->g_px_off[g] + (size_t)b * P) * in_groups * 48 +
+      const __bf16* __restrict__ src = a.in + (btL > 0 ? (size_t)b * btL : (size_t)a.B * d->g_px_off[g] + (size_t)b * P) * in_groups * 48 +
                                        (size_t)(br * a.in_stride_br + cc) * 48;
+      const __bf16* __restrict__ src_pad = a.in + (size_t)a.B * btL * in_groups * 48 + (size_t)(br * a.in_stride_br + cc) * 48;
       for (int pc = wv; pc < npieces; pc += 8) {
         int ci = pc * 64 + lane;
         if (ci >= nchunks16) ci = nchunks16 - 1;             // tail lanes re-read the last piece (lands in slack)
@@ -1163,8 +1185,10 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
         int sub = ci - sp * 7;
         if (sub > 5) sub = 5;                                 // pad chunk: any valid source
         const int rr = (int)(((float)sp + 0.5f) * inv_rw), cx = sp - rr * RW;
+        const int tpx = (R0 + rr) * p + C0 + cx;             // grid pixel = window position t (fold, :1041-1046)
+        const __bf16* __restrict__ row = (btL > 0 && tpx >= btL) ? src_pad : src + (size_t)tpx * in_groups * 48;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + (size_t)((R0 + rr) * p + C0 + cx) * in_groups * 48 + sub * 8),
+            (const __attribute__((address_space(1))) void*)(row + sub * 8),
             (__attribute__((address_space(3))) void*)(rbuf0 + (size_t)buf * a.region_bytes + (size_t)pc * 1024), 16, 0, 0);
       }
     };
@@ -1330,15 +1354,16 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
 
 // ---------------------------------------------------------------- small elementwise stages
 // single-conv mode, stage A: a[n][CP] = zero-extended x
-__global__ void k_embed(const float* __restrict__ x, float* __restrict__ out, const FtnDesc* __restrict__ d, int B,
-                        int L, int C, int CP) {
-  const int N = B * d->total_px;
+__global__ void k_embed(const float* __restrict__ x, float* __restrict__ out, int B, int L, int C, int CP) {
+  // rows n = b*L + t of the window, channels zero-padded to CP, plus one all-zero pad row n = B*L
+  // (the live zero pixels t >= L of every period grid, :1017); the conv folds them (ConvArgs.bt_L)
   const int cq = CP >> 2;
-  const long long total = (long long)N * cq;
+  const long long rows = (long long)B * L + 1;
+  const long long total = rows * cq;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(e / cq), c = (int)(e - (long long)n * cq) * 4;
-    Px px = decode_px(d, x, B, L, C, n, N);
-    *(f4*)(out + (size_t)n * CP + c) = load_x4<false>(px.xrow, c, C);
+    const long long n = e / cq;
+    const int c = (int)(e - n * cq) * 4;
+    *(f4*)(out + (size_t)n * CP + c) = load_x4<false>(n < rows - 1 ? x + (size_t)n * C : nullptr, c, C);
   }
 }
 
@@ -1760,7 +1785,7 @@ static int conv_region_px(int L, int kh, int kw) {
 }
 
 struct WsLayout {
-  size_t off0, off1, off2, off3, total;
+  size_t offA, off0, off1, off2, off3, total;
   int c0, c1;  // channel counts of buf0 / buf1
 };
 
@@ -1773,7 +1798,10 @@ static WsLayout ws_layout(const FtnPlan* pl, int B, int L, int max_groups, int p
   w.c0 = pl->mode == 0 ? CA : pl->CP;                 // a / a'   (mode 1: padded x, then m')
   w.c1 = pl->mode == 0 ? CA : pl->FP;                 // m / m'   (mode 1: conv1 output)
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  w.off0 = FTN_WS_HEAD;
+  // stage A output: one row per window position (+ pad row), shared by all period groups
+  const int bpv = (pl->engine != 0 && pl->mode == 0) ? 6 : 4;                          // P3 = 6 bytes per value
+  w.offA = FTN_WS_HEAD;
+  w.off0 = al(w.offA + ((size_t)B * L + 1) * (pl->mode == 0 ? CA : pl->CP) * bpv);
   w.off1 = al(w.off0 + N * w.c0 * (pl->engine != 0 && pl->mode == 0 ? 6 : 4));   // P3 = 6 bytes per value
   w.off2 = al(w.off1 + N * w.c1 * (pl->engine != 0 && pl->mode == 0 ? 6 : 4));   // R [N][CP]
   w.off3 = al(w.off2 + N * pl->CP * 4);               // G [N][FP] (mode 1)
@@ -1991,6 +2019,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
   hipLaunchKernelGGL(k_guard, dim3(1), dim3(256), 0, st, desc_in, (FtnDesc*)ws, max_groups, px_row);
   FTN_CHECK_LAUNCH();
   const FtnDesc* desc = (const FtnDesc*)ws;
+  float* bufA = (float*)(ws + wl.offA);
   float* buf0 = (float*)(ws + wl.off0);
   float* buf1 = (float*)(ws + wl.off1);
   float* bufR = (float*)(ws + wl.off2);
@@ -2000,7 +2029,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
   const long long Nmax = (long long)B * px_row;
   int tiles_row;
   worst_tiles(L, max_groups, &tiles_row);
-  const int nblk_pw = (int)((Nmax + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));
+  const int nblk_pw = (int)(((long long)B * L + 1 + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));   // stage A: window rows + pad row
   const int nblk_ew = 2048;
   const bool yvec = ((uintptr_t)y & 15) == 0;
   const int nblk_out = (int)(((long long)B * L + 127) / 128);
@@ -2015,7 +2044,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     const int nsplit = pl->engine == 2 ? 1 : 3;
     // A: a = W_in1 x + b
     PwArgs pa = {};
-    pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = buf0; pa.desc = desc;
+    pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = bufA; pa.desc = desc;
     pa.B = B; pa.L = L; pa.C = C; pa.KIN = CP; pa.n_ot = CA / 16; pa.OUTC = CA;
     if (use_bf) { if ((rc = launch_pw<ACT, true, 2>(pa, xvec, nblk_pw, st))) return rc; }
     else if ((rc = launch_pw<ACT, true, 0>(pa, xvec, nblk_pw, st))) return rc;
@@ -2030,14 +2059,14 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
                            pl->cfragbf_per_chunk == 28 &&
                            (size_t)28 * 3 * 1024 + (size_t)pl->n_hchunks * 32 * 2 * sizeof(float) <= 160 * 1024;
     if (use_bf) {
-      cb.in = (const __bf16*)buf0; cb.out = buf1; cb.out_p3 = (mlp_bf || mlp_bf128) ? 1 : 0; cb.bias = wb + pl->b_conv1; cb.desc = desc;
+      cb.in = (const __bf16*)bufA; cb.bt_L = L; cb.out = buf1; cb.out_p3 = (mlp_bf || mlp_bf128) ? 1 : 0; cb.bias = wb + pl->b_conv1; cb.desc = desc;
       cb.B = B; cb.INC = CA; cb.OUTC = CA; cb.nbr = pl->nbr; cb.cin = pl->MP; cb.cout = pl->MP;
       cb.in_stride_br = pl->MP / 16; cb.out_stride_br = pl->MP;
       for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf1[k]); cb.kh[k] = pl->kh[k]; cb.kw[k] = pl->kw[k]; }
     }
     // B: m = conv(a)
     ConvArgs ca = {};
-    ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CA; ca.OUTC = CA;
+    ca.in = bufA; ca.bt_L = L; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CA; ca.OUTC = CA;
     ca.nbr = pl->nbr; ca.cin = pl->MP; ca.cout = pl->MP; ca.in_stride_br = pl->MP; ca.out_stride_br = pl->MP;
     for (int k = 0; k < pl->nbr; ++k) { ca.W[k] = wb + pl->w_conv1[k]; ca.kh[k] = pl->kh[k]; ca.kw[k] = pl->kw[k]; }
     if (use_bf) { if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st))) return rc; }
@@ -2072,10 +2101,10 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     } else if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
     prof_mark(3, st);
     // D: m' = conv(a')
-    ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
+    ca.in = buf0; ca.bt_L = 0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
     if (use_bf) {
-      cb.bias = wb + pl->b_conv2; cb.out_p3 = 0;
+      cb.in = (const __bf16*)buf0; cb.bt_L = 0; cb.bias = wb + pl->b_conv2; cb.out_p3 = 0;
       for (int k = 0; k < pl->nbr; ++k) cb.W[k] = (const __bf16*)(wb + pl->w_convbf2[k]);
       if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st))) return rc;
     } else if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
@@ -2096,12 +2125,12 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     prof_mark(5, st);
   } else {
     // A: zero-extended copy of x
-    hipLaunchKernelGGL(k_embed, dim3(nblk_ew), dim3(256), 0, st, x, buf0, desc, B, L, C, CP);
+    hipLaunchKernelGGL(k_embed, dim3(nblk_ew), dim3(256), 0, st, x, bufA, B, L, C, CP);
     FTN_CHECK_LAUNCH();
     prof_mark(1, st);
     // B: m = conv_merged(x) (+ folded proj bias)
     ConvArgs ca = {};
-    ca.in = buf0; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CP; ca.OUTC = FP;
+    ca.in = bufA; ca.bt_L = L; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CP; ca.OUTC = FP;
     ca.nbr = 1; ca.cin = CP; ca.cout = FP; ca.in_stride_br = 0; ca.out_stride_br = 0;
     ca.W[0] = wb + pl->w_conv1[0]; ca.kh[0] = pl->kh[0]; ca.kw[0] = pl->kw[0];
     if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
@@ -2121,7 +2150,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
     prof_mark(3, st);
     // D: m' = conv_merged'(g)
-    ca.in = bufG; ca.out = buf0; ca.bias = wb + pl->b_conv2; ca.INC = FP; ca.OUTC = CP; ca.cin = FP; ca.cout = CP;
+    ca.in = bufG; ca.bt_L = 0; ca.out = buf0; ca.bias = wb + pl->b_conv2; ca.INC = FP; ca.OUTC = CP; ca.cin = FP; ca.cout = CP;
     ca.W[0] = wb + pl->w_conv2[0];
     if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(4, st);

@@ -40,7 +40,10 @@ def _full_size_block_properties(ftn, dev, B, L, C, K, engine, planted, rows):
     assert blk._last_backend == "hip"
     assert torch.equal(y1, y2)                                    # deterministic (no atomics)
     periods = blk.period_selector.last_selected_periods.tolist()
-    assert sorted(periods) == sorted(planted)                     # integer period indices, bit-exact
+    want = orc.period_select(torch.from_numpy(xh), K, L)          # the selector alone is cheap on the CPU
+    assert periods == want.periods                                # integer period indices, bit-exact, score order
+    assert blk.period_selector.last_frequency_indices.tolist() == want.freq_idx
+    assert sorted(periods) == sorted(planted) and want.topk_gap > 0.1
     assert blk._last_group_count == len(set(planted))
     assert torch.isfinite(y1).all()
     # rows are independent once periods and per-row amplitudes are fixed -> CPU oracle on a few rows
@@ -64,7 +67,8 @@ def test_c1_full_size_fp32_engine(ftn, dev):
 def test_c3_full_size_block(engine, ftn, dev):
     """BASELINE configs[3] (one GPU's TimesBlock): B=256 L=720 d_model=128 d_ff=512 k=5 - 0.95 M grid pixels,
     the flat pixel index and the 1.8 GB workspace at their real sizes."""
-    _full_size_block_properties(ftn, dev, 256, 720, 128, 5, engine, [24, 168, 144, 12, 7], [0, 100, 255])
+    # planted 168 is not a divisor of 720: its energy lands in rFFT bin 4 -> period ceil(720/4) = 180
+    _full_size_block_properties(ftn, dev, 256, 720, 128, 5, engine, [24, 180, 144, 12, 7], [0, 100, 255])
 
 
 class _ReplaySelector(torch.nn.Module):
