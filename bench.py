@@ -193,7 +193,7 @@ def run_rank(args) -> None:
     alt_ms = {}
     if world == 1 and not args.no_extras:
         # the other conv/chain arithmetic, timed briefly for comparison (same weights, same input)
-        for alt in ("f32", "bf16x3", "bf16"):    # "bf16" = BASELINE configs[2] (plain bf16 operands, fp32 accumulate)
+        for alt in ("f32", "bf16x3", "f16x2", "bf16"):    # "bf16" = BASELINE configs[2] (plain bf16 operands, fp32 accumulate)
             if alt == engine:
                 continue
             blk.engine = alt
@@ -285,7 +285,7 @@ def run_rank(args) -> None:
         # the bf16 pipe is 2500/6; plain bf16 (one product) 2500.  `frac_pipe` is the pipe-occupancy view of the
         # same launch (all six products and the K padding counted against 2500).
         flops_alg = 2.0 * macs[dom] * px
-        nprod = {"f32": 1, "bf16x3": 6, "bf16": 1}[engine]
+        nprod = {"f32": 1, "bf16x3": 6, "f16x2": 3, "bf16": 1}[engine]
         on_mfma = dom in (1, 2, 3)
         peak_tf = FP32_MFMA_PEAK_TF if (engine == "f32" or not on_mfma) else BF16_MFMA_PEAK_TF / nprod
         achieved = flops_alg / (stage_ms[dom] * 1e-3) / 1e12 if stage_ms[dom] > 0 else 0.0
@@ -319,12 +319,13 @@ def run_rank(args) -> None:
             "value": value, "unit": "series/s", "n_gpus": dist_world if use_dist else 1, "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if engine == "f32" else ("f32 via bf16x3 split" if engine == "bf16x3" else "bf16"),
+            "dtype": {"f32": "f32", "bf16x3": "f32 via bf16x3 split", "f16x2": "f32 via f16x2 split", "bf16": "bf16"}[engine],
             "data": "synthetic",
             "config": {"workload": f"timesblock_fwd B={B}/gpu L={L} N={NS} d_model={C} d_ff={F} kernels=3/5/7 "
                                    f"ratio=4 k_periods={K}; arithmetic engine={engine} "
-                                   "(f32: exact fp32 MFMA; bf16x3: three bf16 pieces per fp32 value, six partial "
-                                   "products on the bf16 matrix pipe, fp32 accumulate, error <= an fp32 FMA chain; "
+                                   "(f32: exact fp32 MFMA; f16x2: two fp16 pieces per activation, three per prescaled "
+                                   "weight, three partial products per fp32 multiply on the fp16 matrix pipe, fp32 "
+                                   "accumulate, 2^-22 per operand; bf16x3: three bf16 pieces, six products; all pass the "
                                    "same 1e-4 parity tests)",
                        "engine": engine, "other_engine_ms_per_step": alt_ms,
                        "windows_per_s": world * B / (elapsed / args.steps), "periods": periods, "groups": G,
@@ -336,8 +337,8 @@ def run_rank(args) -> None:
             "roofline": {"bound": "mfma", "kernel": STAGES[dom], "achieved": achieved, "peak": peak_tf,
                          "unit": "TFLOP/s", "frac": achieved / peak_tf, "traffic": traffic,
                          "definition": "achieved = executed (folded, unpadded) fp32 multiply-adds x2 per launch / avg "
-                                       "launch time (HIP events in the timed region); peak = dense MFMA peak of the "
-                                       "pipe / products per fp32 multiply (6 for bf16x3)",
+                                       "launch time (HIP events in the timed region); peak = dense 16-bit MFMA peak / "
+                                       "products per fp32 multiply (3 for f16x2, 6 for bf16x3); fp32 MFMA peak for f32",
                          "frac_algorithmic": achieved / peak_tf, "frac_pipe": frac_pipe,
                          "flops_per_launch": flops_alg, "avg_launch_ms": stage_ms[dom],
                          "stage_ms": dict(zip(STAGES, [round(v, 4) for v in stage_ms])),

@@ -212,6 +212,62 @@ __device__ __forceinline__ void store_p3(__bf16* __restrict__ grp, int q, f4 v) 
   *(u2*)(grp + 32 + 4 * q) = u2{pc[2][0], pc[2][1]};
 }
 
+// ---- f16x2 split arithmetic ("engine f16x2", NS == 2 in the kernels) -----------------------------
+// An fp32 activation x is carried as TWO fp16 pieces: hi = fp16(x) (round to nearest) and
+// lo' = fp16((x - hi) * 2^11); x - hi is exact in fp32 and at most half an fp16 ulp of x, so lo' has the
+// magnitude of x / 2 at most (no underflow while x itself is an fp16 normal) and hi + lo' 2^-11
+// reproduces x to 2^-22 relative.  Weights are split on the host into three fp16 pieces of the
+// power-of-two-prescaled matrix W~ = 2^s W:  A1 = fp16(W~),  A2 = fp16(A1 2^-11),  A3 = fp16(W~ - A1),
+// and a product is the three terms  A1 hi + A2 lo' + A3 hi  on v_mfma_f32_16x16x32_f16 with one fp32
+// accumulator (the hi-lo, lo-hi and hi-hi partial products; lo-lo is below 2^-22).  Half the MFMAs and
+// two thirds of the activation bytes of the bf16x3 scheme at the same accuracy (pack.py);
+// the accumulator carries the scale 2^s (biases are prescaled on the host) and the consumer multiplies by
+// 2^-s.  Range: |x| must stay below 65504, the fp16 maximum - beyond it the pieces are +-inf and the
+// result is non-finite (never silently wrong); engines bf16x3 / f32 have the full fp32 range.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f4 mfma_h(bf8 a, bf8 b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+#define FTN_H2_LOSCALE 2048.0f
+
+// NV (even) fp32 values -> hi and lo' piece vectors, NV/2 dwords each (v_cvt_pk_f16_f32: round to nearest even)
+template <int NV>
+__device__ __forceinline__ void split_h2(const float (&v)[NV], unsigned (&out)[2][NV / 2]) {
+#pragma unroll
+  for (int k = 0; k < NV / 2; ++k) {
+    const h2v hi = {(_Float16)v[2 * k], (_Float16)v[2 * k + 1]};
+    const float r0 = (v[2 * k] - (float)hi[0]) * FTN_H2_LOSCALE;
+    const float r1 = (v[2 * k + 1] - (float)hi[1]) * FTN_H2_LOSCALE;
+    const h2v lo = {(_Float16)r0, (_Float16)r1};
+    out[0][k] = __builtin_bit_cast(unsigned, hi);
+    out[1][k] = __builtin_bit_cast(unsigned, lo);
+  }
+}
+
+// "H2" activation layout: per pixel, per group of 16 channels: [hi 16][lo' 16] fp16 (64 bytes).
+__device__ __forceinline__ void store_h2(__bf16* __restrict__ grp, int q, f4 v) {
+  const float vv[4] = {v[0], v[1], v[2], v[3]};
+  unsigned pc[2][2];
+  split_h2<4>(vv, pc);
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  *(u2*)(grp + 4 * q) = u2{pc[0][0], pc[0][1]};
+  *(u2*)(grp + 16 + 4 * q) = u2{pc[1][0], pc[1][1]};
+}
+
+// Piece-count-generic forms used by the kernels: NS = 3 bf16x3 (P3, 96 B), NS = 2 f16x2 (H2, 64 B),
+// NS = 1 plain bf16 (reads only the hi piece of a P3 record).
+template <int NS> struct PxFmt { static constexpr int BYTES = 96; static constexpr int ELEMS = 48; static constexpr int NW = NS; };
+template <> struct PxFmt<2> { static constexpr int BYTES = 64; static constexpr int ELEMS = 32; static constexpr int NW = 3; };
+
+template <int NS>
+__device__ __forceinline__ void store_px(__bf16* __restrict__ grp, int q, f4 v) {
+  if (NS == 2) store_h2(grp, q, v);
+  else store_p3(grp, q, v);
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_fn(float v) {
   if (ACT == 1) return v > 0.0f ? v : 0.0f;

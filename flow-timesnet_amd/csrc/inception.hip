@@ -162,8 +162,9 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
           const int ch = 16 * (og + o) + 4 * q;
           if (EPI == 0) {
             *(f4*)(a.out + (size_t)px[u].n * a.OUTC + ch) = acc[o][u];
-          } else if (EPI == 2) {   // three bf16 pieces per value (input of the bf16x3 conv engine)
-            store_p3((__bf16*)a.out + ((size_t)px[u].n * (a.OUTC >> 4) + (og + o)) * 48, q, acc[o][u]);
+          } else if (EPI == 2 || EPI == 3) {   // bf16x3 (P3) / f16x2 (H2) pieces: input of the split conv engines
+            constexpr int NSP = EPI == 3 ? 2 : 3;
+            store_px<NSP>((__bf16*)a.out + ((size_t)px[u].n * (a.OUTC >> 4) + (og + o)) * PxFmt<NSP>::ELEMS, q, acc[o][u]);
           } else {
             float* rp = a.R + (size_t)px[u].n * a.RC + ch;
             const f4 r = *(const f4*)rp;
@@ -205,7 +206,7 @@ struct MlpArgs {
   int n_ot;              // total output tiles (n_oa + CP/16 when res2 is a conv)
   int res2_ident;        // 1: r = g - x  (FP == CP), taken from the hidden tiles
   int n_hchunks, cfrag_per_chunk;
-  int outA_p3;           // 1: write a' as three bf16 pieces (bf16x3 conv engine)
+  int outA_p3;           // 1: write a' as three bf16 pieces (bf16x3 conv engine), 2: two fp16 pieces (f16x2)
   unsigned long long* dbg; size_t dbg_cap;
 };
 
@@ -437,7 +438,8 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
       for (int u = 0; u < NPX; ++u) {
         if (!px[u].ok) continue;
         if (o < a.n_oa) {
-          if (a.outA_p3) store_p3((__bf16*)a.outA + ((size_t)px[u].n * (a.AC >> 4) + o) * 48, q, oacc[o][u]);
+          if (a.outA_p3 == 2) store_h2((__bf16*)a.outA + ((size_t)px[u].n * (a.AC >> 4) + o) * 32, q, oacc[o][u]);
+          else if (a.outA_p3) store_p3((__bf16*)a.outA + ((size_t)px[u].n * (a.AC >> 4) + o) * 48, q, oacc[o][u]);
           else *(f4*)(a.outA + (size_t)px[u].n * a.AC + 16 * o + 4 * q) = oacc[o][u];
         } else {
           const int ch = 16 * (o - a.n_oa) + 4 * q;
@@ -469,11 +471,15 @@ struct MlpBfArgs {
   int B, L, C, CP, FP, KM, AC;
   int nsKM, nsCP;        // K=32 slabs of layer 1 / of the residual (each <= 2)
   int n_oa, n_ot, n_hchunks, per_chunk;
+  // f16x2 engine (NS == 2): the accumulators carry the power-of-two prescale of their weight matrix (bo / br /
+  // bc then point at biases prescaled the same way): z = acc_o * inv_o;  acc_r starts as act(z) * sc_r + br~
+  // and g = act(acc_r * inv_r);  a' = acc * inv_a (tiles < n_oa),  r = acc * inv_r2 - x.  All 1 otherwise.
+  float inv_o, sc_r, inv_r, inv_a, inv_r2;
   unsigned long long* dbg; size_t dbg_cap;
 };
 
 template <int NS>
-__device__ __forceinline__ f4 chain_bf(const bf8 (&ap)[NS], const bf8 (&bp)[NS], f4 c) {
+__device__ __forceinline__ f4 chain_bf(const bf8 (&ap)[PxFmt<NS>::NW], const bf8 (&bp)[NS], f4 c) {
   if (NS == 3) {
     c = mfma_bf(ap[0], bp[2], c);
     c = mfma_bf(ap[2], bp[0], c);
@@ -481,19 +487,34 @@ __device__ __forceinline__ f4 chain_bf(const bf8 (&ap)[NS], const bf8 (&bp)[NS],
     c = mfma_bf(ap[0], bp[1], c);
     c = mfma_bf(ap[1], bp[0], c);
   }
+  if (NS == 2) {                       // f16x2: A2 lo' + A3 hi + A1 hi (ftn_common.h), small terms first
+    c = mfma_h(ap[1], bp[1], c);
+    c = mfma_h(ap[2], bp[0], c);
+    return mfma_h(ap[0], bp[0], c);
+  }
   return mfma_bf(ap[0], bp[0], c);
 }
 
-// eight fp32 values -> NS bf16 pieces of 8 (exact truncation split, ftn_common.h)
+// eight fp32 values -> NS pieces of 8 (bf16: exact truncation split; fp16: hi + scaled remainder, ftn_common.h)
 template <int NS>
 __device__ __forceinline__ void split_pieces(const float (&v)[8], bf8 (&out)[NS]) {
-  unsigned pc[NS][4];
-  split_trunc<NS, 8>(v, pc);
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  if (NS == 2) {
+    unsigned pc[2][4];
+    split_h2<8>(v, pc);
 #pragma unroll
-  for (int p = 0; p < NS; ++p) {
-    const u4 w = {pc[p][0], pc[p][1], pc[p][2], pc[p][3]};
-    out[p] = __builtin_bit_cast(bf8, w);
+    for (int p = 0; p < 2; ++p) {
+      const u4 w = {pc[p][0], pc[p][1], pc[p][2], pc[p][3]};
+      out[p] = __builtin_bit_cast(bf8, w);
+    }
+  } else {
+    unsigned pc[NS][4];
+    split_trunc<NS, 8>(v, pc);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+      const u4 w = {pc[p][0], pc[p][1], pc[p][2], pc[p][3]};
+      out[p] = __builtin_bit_cast(bf8, w);
+    }
   }
 }
 
@@ -532,6 +553,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
   const int CP = a.CP;
   const int nsKM = a.nsKM, nsCP = a.nsCP, n_ot = EXACT ? OTM : a.n_ot;
   const int kmg = a.KM >> 4;                                  // 16-channel groups of m
+  constexpr int NWP = PxFmt<NS>::NW;                          // weight pieces per fragment
+  constexpr int PXE = PxFmt<NS>::ELEMS;                       // 16-bit elements per pixel and 16-channel group
   // B operands that do not depend on the hidden chunk
   bf8 mp[2][NPX][NS], xp[2][NPX][NS];
   f4 xraw[2][NPX][2];
@@ -540,7 +563,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
 #pragma unroll
     for (int u = 0; u < NPX; ++u) {
       const int grp = 2 * s + (qa >> 1);
-      const __bf16* __restrict__ src = a.m + ((size_t)px[u].n * kmg + (grp < kmg ? grp : 0)) * 48 + (qa & 1) * 8;
+      const __bf16* __restrict__ src = a.m + ((size_t)px[u].n * kmg + (grp < kmg ? grp : 0)) * PXE + (qa & 1) * 8;
 #pragma unroll
       for (int pz = 0; pz < NS; ++pz) mp[s][u][pz] = *(const bf8*)(src + pz * 16);
       xraw[s][u][0] = s < nsCP ? load_x4<XVEC>(px[u].xrow, 32 * s + 8 * qa, a.C) : f4{0.f, 0.f, 0.f, 0.f};
@@ -599,14 +622,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
     }
     f4 h[2][NPX];
     bf8 hp[NPX][NS];
-    bf8 fa[NS], fb[NS];
-    auto ldfrag = [&](int f, bf8 (&ap)[NS]) {
+    bf8 fa[NWP], fb[NWP];
+    auto ldfrag = [&](int f, bf8 (&ap)[NWP]) {
 #pragma unroll
-      for (int pz = 0; pz < NS; ++pz) ap[pz] = *(const bf8*)(wl + (size_t)(f * 3 + pz) * 1024);
+      for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(wl + (size_t)(f * 3 + pz) * 1024);
     };
     auto gelu_u = [&](int t, int u, bool addbr) {
-      h[t][u] = act4<ACT>(h[t][u]);
-      if (addbr) h[t][u] += br_t[t];
+      if (NS == 2) {                                           // undo / apply the weight prescales (see MlpBfArgs)
+        h[t][u] = act4<ACT>(h[t][u] * (addbr ? a.inv_o : a.inv_r));
+        if (addbr) h[t][u] = h[t][u] * a.sc_r + br_t[t];
+      } else {
+        h[t][u] = act4<ACT>(h[t][u]);
+        if (addbr) h[t][u] += br_t[t];
+      }
     };
     auto split_u = [&](int u) {
       float hv[8];
@@ -707,10 +735,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
       for (int u = 0; u < NPX; ++u) {
         if (!px[u].ok) continue;
         if (o < a.n_oa) {
-          store_p3(a.outA + ((size_t)px[u].n * (a.AC >> 4) + o) * 48, qa, oacc[o][u]);
+          store_px<NS == 2 ? 2 : 3>(a.outA + ((size_t)px[u].n * (a.AC >> 4) + o) * PXE, qa,
+                                    NS == 2 ? oacc[o][u] * a.inv_a : oacc[o][u]);
         } else {
           const int ch = 16 * (o - a.n_oa) + 4 * qa;
-          *(f4*)(a.outR + (size_t)px[u].n * CP + ch) = oacc[o][u] - load_x4<XVEC>(px[u].xrow, ch, a.C);
+          const f4 rv = NS == 2 ? oacc[o][u] * a.inv_r2 : oacc[o][u];
+          *(f4*)(a.outR + (size_t)px[u].n * CP + ch) = rv - load_x4<XVEC>(px[u].xrow, ch, a.C);
         }
       }
     }
@@ -746,12 +776,14 @@ __global__ __launch_bounds__(512, 2) void k_mlp_bf_c128(MlpBfArgs a) {
   const Px px = decode_px(d, a.x, a.B, a.L, a.C, n0 + j, N);
   const int CP = a.CP;
   const int kmg = a.KM >> 4;
+  constexpr int NWP = PxFmt<NS>::NW;
+  constexpr int PXE = PxFmt<NS>::ELEMS;
   bf8 mp[SKM][NS], xp[SCP][NS];
   f4 xraw[SCP][2];
 #pragma unroll
   for (int s = 0; s < SKM; ++s) {
     const int grp = 2 * s + (qa >> 1);
-    const __bf16* __restrict__ src = a.m + ((size_t)px.n * kmg + (grp < kmg ? grp : 0)) * 48 + (qa & 1) * 8;
+    const __bf16* __restrict__ src = a.m + ((size_t)px.n * kmg + (grp < kmg ? grp : 0)) * PXE + (qa & 1) * 8;
 #pragma unroll
     for (int pz = 0; pz < NS; ++pz) mp[s][pz] = *(const bf8*)(src + pz * 16);
   }
@@ -799,27 +831,28 @@ __global__ __launch_bounds__(512, 2) void k_mlp_bf_c128(MlpBfArgs a) {
     if (active) {
       f4 h[2] = {bo_t[0], bo_t[1]};
       bf8 hp[NS];
-      bf8 fr[2][NS];
-      auto ldfrag = [&](int f, bf8 (&ap)[NS]) {
+      bf8 fr[2][NWP];
+      auto ldfrag = [&](int f, bf8 (&ap)[NWP]) {
 #pragma unroll
-        for (int pz = 0; pz < NS; ++pz) ap[pz] = *(const bf8*)(wl + (size_t)(f * 3 + pz) * 1024);
+        for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(wl + (size_t)(f * 3 + pz) * 1024);
       };
       ldfrag(0, fr[0]);
 #pragma unroll
       for (int f = 0; f < NFR; ++f) {
         if (f + 1 < NFR) ldfrag(f + 1, fr[(f + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
-        const bf8 (&cur)[NS] = fr[f & 1];
+        const bf8 (&cur)[NWP] = fr[f & 1];
         if (f < SKM) h[0] = chain_bf<NS>(cur, mp[f], h[0]);                         // layer 1, hidden tile 0
         else if (f < 2 * SKM) h[1] = chain_bf<NS>(cur, mp[f - SKM], h[1]);          // layer 1, hidden tile 1
         else if (f < 2 * SKM + SCP) h[0] = chain_bf<NS>(cur, xp[f - 2 * SKM], h[0]);               // + res1(x)
         else if (f < 2 * SKM + 2 * SCP) h[1] = chain_bf<NS>(cur, xp[f - 2 * SKM - SCP], h[1]);
         else oacc[f - 2 * SKM - 2 * SCP] = chain_bf<NS>(cur, hp, oacc[f - 2 * SKM - 2 * SCP]);    // a' | res2
-        if (f == SKM - 1) h[0] = act4<ACT>(h[0]) + br_t[0];                          // act, then the residual adds on
-        if (f == 2 * SKM - 1) h[1] = act4<ACT>(h[1]) + br_t[1];
-        if (f == 2 * SKM + SCP - 1) h[0] = act4<ACT>(h[0]);                          // TimesBlock's mid activation
+        // act, then the residual adds on; NS == 2 undoes / applies the weight prescales (see MlpBfArgs)
+        if (f == SKM - 1) h[0] = NS == 2 ? act4<ACT>(h[0] * a.inv_o) * a.sc_r + br_t[0] : act4<ACT>(h[0]) + br_t[0];
+        if (f == 2 * SKM - 1) h[1] = NS == 2 ? act4<ACT>(h[1] * a.inv_o) * a.sc_r + br_t[1] : act4<ACT>(h[1]) + br_t[1];
+        if (f == 2 * SKM + SCP - 1) h[0] = act4<ACT>(NS == 2 ? h[0] * a.inv_r : h[0]);   // TimesBlock's mid activation
         if (f == 2 * SKM + 2 * SCP - 1) {
-          h[1] = act4<ACT>(h[1]);
+          h[1] = act4<ACT>(NS == 2 ? h[1] * a.inv_r : h[1]);
           float hv[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { hv[e] = h[0][e]; hv[4 + e] = h[1][e]; }
@@ -838,10 +871,11 @@ __global__ __launch_bounds__(512, 2) void k_mlp_bf_c128(MlpBfArgs a) {
 #pragma unroll
   for (int o = 0; o < OTM; ++o) {
     if (o < a.n_oa) {
-      store_p3(a.outA + ((size_t)px.n * (a.AC >> 4) + o) * 48, qa, oacc[o]);
+      store_px<NS == 2 ? 2 : 3>(a.outA + ((size_t)px.n * (a.AC >> 4) + o) * PXE, qa, NS == 2 ? oacc[o] * a.inv_a : oacc[o]);
     } else {
       const int ch = 16 * (o - a.n_oa) + 4 * qa;
-      *(f4*)(a.outR + (size_t)px.n * CP + ch) = oacc[o] - load_x4<XVEC>(px.xrow, ch, a.C);
+      const f4 rv = NS == 2 ? oacc[o] * a.inv_r2 : oacc[o];
+      *(f4*)(a.outR + (size_t)px.n * CP + ch) = rv - load_x4<XVEC>(px.xrow, ch, a.C);
     }
   }
 }
@@ -1105,33 +1139,38 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 // double-buffered (row i+1 is requested before row i is computed), so neither is on the
 // critical path.  NS = 1 drops the mid/lo pieces (plain bf16, BASELINE configs[2]).
 struct ConvBfArgs {
-  const __bf16* in;      // P3 [N][INC/16][3][16]
-  void* out;             // fp32 [N][OUTC] or P3 [N][OUTC/16][3][16]
+  const __bf16* in;      // P3 / H2 [rows][INC/16][pieces][16]
+  void* out;             // fp32 [N][OUTC] or P3 / H2 [N][OUTC/16][pieces][16]
   const __bf16* W[FTN_MAXBR];  // per branch [cc][co][slab][piece][lane][8]
-  const float* bias;
+  const float* bias;     // f16x2: prescaled by the branch's weight scale
   const FtnDesc* desc;
   int B, INC, OUTC, out_p3;
   int nbr, cin, cout, in_stride_br, out_stride_br, nchunk;
-  int region_bytes;      // one region buffer incl. the 96-byte zero pixel at its end
+  int plane_bytes;       // one piece plane of a region buffer (32 B per pixel) incl. its zero pixel at the end
+  int region_bytes;      // one region buffer = pieces x plane_bytes
   int wbytes;            // weight fragment bytes in LDS
   int bpw;               // batch rows per workgroup
   int sgroup;            // K=32 slabs whose weight fragments are resident at a time (>= max slabs: all of them)
   int kh[FTN_MAXBR], kw[FTN_MAXBR], order[FTN_MAXBR];
   int bt_L;              // as ConvArgs.bt_L: > 0 = input rows per window position + one pad row
+  float inv[FTN_MAXBR];  // f16x2: 2^-s of the branch's prescaled weights (applied to the accumulators)
   unsigned long long* dbg; size_t dbg_cap;
 };
 
 #define CBF_NU 3          // 16-pixel units per wave: 8 waves x 3 x 16 >= FTN_TILE_PX
-#define P3_PX_BYTES 96    // one pixel of one 16-channel group in global memory: 3 pieces x 16 bf16
-#define P3_LDS_STRIDE 112 // LDS pixel stride: 96 + 16 pad bytes, so the 16 pixels of a ds_read_b128 lane
-                          // group fall on 16 distinct bank quads (96 would be 2-way conflicted).  PMC still
-                          // reports ~2.6 conflict cycles per LDS instruction here (4.0 cycles conflict-free);
-                          // giving out-of-grid lanes bank-matched zero pixels did not change that, and the
-                          // next coprime stride (144 B) does not fit two region buffers plus the 7x7 weights.
+// LDS image of a staged region: one PLANE per piece, 32 bytes per pixel = [channels 0-7][channels 8-15] of that
+// piece.  A ds_read_b128 is served in four groups of 16 lanes - {0-3,12-15,20-27}, {4-11,16-19,28-31} and the
+// same + 32 (MI355X_MICROARCH.md, LDS) - and a lane (j = lane & 15, qa = lane >> 4) reads pixel j's half qa & 1:
+// with a 32-byte pixel stride the eight half-0 lanes of a group fall on the even 16-byte bank quads and its eight
+// half-1 lanes on the odd ones, all distinct, for every tap offset (a constant shift).  Round 1's pixel-major
+// image (96 B of pieces + 16 B pad per pixel) put seven of those sixteen lanes on a shared quad.
+#define CBF_PX_BYTES 32
 
 template <int NCO, int NS>
 __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  constexpr int NWP = PxFmt<NS>::NW;                          // weight pieces
+  constexpr int PXE = PxFmt<NS>::ELEMS;                       // 16-bit elements per pixel and 16-channel group in memory
   const FtnDesc* __restrict__ d = a.desc;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -1142,11 +1181,15 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
   const int nco_tot = a.cout >> 4, co0 = chunk * NCO, ncc = a.cin >> 4;
   char* __restrict__ wl = ldsb;
   char* __restrict__ rbuf0 = ldsb + a.wbytes;
-  const int zoff = a.region_bytes - P3_LDS_STRIDE;         // zero pixel at the end of each region buffer
+  const int plane = a.plane_bytes;
+  const int zoff = plane - 64 + (qa & 1) * 16;               // zero pixel at the end of every plane
   const int b_begin = blockIdx.y * a.bpw, b_end = min(a.B, b_begin + a.bpw);
   const int G = d->n_groups, tiles_total = d->tiles_per_row;
-  // zero pixels of both region buffers (never overwritten by the DMA)
-  if (threadIdx.x < 14) *(f4*)(rbuf0 + (threadIdx.x / 7) * a.region_bytes + zoff + (threadIdx.x % 7) * 16) = f4{0.f, 0.f, 0.f, 0.f};
+  // zero pixels of every plane of both region buffers (never overwritten by the DMA)
+  if (threadIdx.x < 2 * NS * 4) {
+    const int pl = threadIdx.x >> 2;                           // (buffer, piece) plane index
+    *(f4*)(rbuf0 + (size_t)(pl / NS) * a.region_bytes + (size_t)(pl % NS) * plane + plane - 64 + (threadIdx.x & 3) * 16) = f4{0.f, 0.f, 0.f, 0.f};
+  }
   const size_t wgid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   stamp(a.dbg, a.dbg_cap, wgid, 0);
   if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) { a.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime(); a.dbg[wgid * 8 + 4] = (unsigned long long)ntaps; a.dbg[wgid * 8 + 5] = 0; }
@@ -1169,27 +1212,28 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
     const int in_groups = a.INC >> 4;
     const float inv_tw = 1.0f / (float)tw, inv_rw = 1.0f / (float)RW;
     const unsigned kmh = (1u << kh) - 1u, kmw = (1u << kw) - 1u;
-    const int nchunks16 = RH * RW * 7;                     // 16-byte pieces of one region (6 data + 1 pad per pixel)
-    const int npieces = (nchunks16 + 63) >> 6;             // 1-KiB DMA instructions
+    const int nchunks16 = RH * RW * 2;                     // 16-byte chunks of one plane (two per pixel)
+    const int ppp = (nchunks16 + 63) >> 6;                 // 1-KiB DMA instructions per plane
 
-    // region of batch row b, channel group cc -> buffer `buf`
+    // region of batch row b, channel group cc -> buffer `buf`: every lane fetches the 16 bytes (pixel, piece,
+    // channel half) that belong at its linear LDS position, so the fold (:1041-1046), the clipped halo and the
+    // plane split all happen in the DMA's source addresses
     const int btL = a.bt_L;
     auto dma_region = [&](int b, int cc, int buf) {
-      const __bf16* __restrict__ src = a.in + (btL > 0 ? (size_t)b * btL : (size_t)a.B * d->g_px_off[g] + (size_t)b * P) * in_groups * 48 +
-                                       (size_t)(br * a.in_stride_br + cc) * 48;
-      const __bf16* __restrict__ src_pad = a.in + (size_t)a.B * btL * in_groups * 48 + (size_t)(br * a.in_stride_br + cc) * 48;
-      for (int pc = wv; pc < npieces; pc += 8) {
-        int ci = pc * 64 + lane;
-        if (ci >= nchunks16) ci = nchunks16 - 1;             // tail lanes re-read the last piece (lands in slack)
-        const int sp = (int)(((float)ci + 0.5f) * (1.0f / 7.0f));
-        int sub = ci - sp * 7;
-        if (sub > 5) sub = 5;                                 // pad chunk: any valid source
+      const __bf16* __restrict__ src = a.in + (btL > 0 ? (size_t)b * btL : (size_t)a.B * d->g_px_off[g] + (size_t)b * P) * in_groups * PXE +
+                                       (size_t)(br * a.in_stride_br + cc) * PXE;
+      const __bf16* __restrict__ src_pad = a.in + (size_t)a.B * btL * in_groups * PXE + (size_t)(br * a.in_stride_br + cc) * PXE;
+      for (int pc = wv; pc < NS * ppp; pc += 8) {
+        const int pz = pc / ppp, pi = pc - pz * ppp;
+        int ci = pi * 64 + lane;
+        if (ci >= nchunks16) ci = nchunks16 - 1;             // tail lanes re-read the last chunk (lands in the plane's slack)
+        const int sp = ci >> 1, half = ci & 1;
         const int rr = (int)(((float)sp + 0.5f) * inv_rw), cx = sp - rr * RW;
         const int tpx = (R0 + rr) * p + C0 + cx;             // grid pixel = window position t (fold, :1041-1046)
-        const __bf16* __restrict__ row = (btL > 0 && tpx >= btL) ? src_pad : src + (size_t)tpx * in_groups * 48;
+        const __bf16* __restrict__ row = (btL > 0 && tpx >= btL) ? src_pad : src + (size_t)tpx * in_groups * PXE;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(row + sub * 8),
-            (__attribute__((address_space(3))) void*)(rbuf0 + (size_t)buf * a.region_bytes + (size_t)pc * 1024), 16, 0, 0);
+            (const __attribute__((address_space(1))) void*)(row + pz * 16 + half * 8),
+            (__attribute__((address_space(3))) void*)(rbuf0 + (size_t)buf * a.region_bytes + (size_t)pz * plane + (size_t)pi * 1024), 16, 0, 0);
       }
     };
     // weight fragments of slabs [g0, g1) of channel chunk cc -> LDS slots [o][slab - g0][piece]
@@ -1223,7 +1267,7 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
       if (!pok[u]) idx = 0;
       const int r = (int)(((float)idx + 0.5f) * inv_tw), c = idx - r * tw;
       const int ri = r0 + r, ci = c0 + c;
-      lbase[u] = ((ri - R0 - hy) * RW + (ci - C0 - hx)) * P3_LDS_STRIDE + (qa & 1) * 16;
+      lbase[u] = ((ri - R0 - hy) * RW + (ci - C0 - hx)) * CBF_PX_BYTES + (qa & 1) * 16;
       oidx[u] = ri * p + ci;
       const int rlo = max(0, hy - ri), rhi = min(kh, cycles + hy - ri);
       const int clo = max(0, hx - ci), chi = min(kw, p + hx - ci);
@@ -1264,44 +1308,32 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
         int tl = qa >> 1;
         int dy = tl / kw, dx = tl - dy * kw;
         int sload = 0, g0 = 0, g1 = SG;                       // resident slab group [g0, g1)
-        auto load_slab = [&](bf8 (&bp)[CBF_NU][NS], bf8 (&ap)[NCO][NS]) {
+        auto load_slab = [&](bf8 (&bp)[CBF_NU][NS], bf8 (&ap)[NCO][NWP]) {
           const bool tapok = tl < ntaps;
-          const int toff = (dy * RW + dx) * P3_LDS_STRIDE;
+          const int toff = (dy * RW + dx) * CBF_PX_BYTES;
 #pragma unroll
           for (int u = 0; u < CBF_NU; ++u) {
             const bool v = tapok && (((rmask[u] >> dy) & (cmask[u] >> dx) & 1u) != 0u);
             const char* __restrict__ src = reg + (v ? lbase[u] + toff : zoff);
 #pragma unroll
-            for (int pz = 0; pz < NS; ++pz) bp[u][pz] = *(const bf8*)(src + pz * 32);
+            for (int pz = 0; pz < NS; ++pz) bp[u][pz] = *(const bf8*)(src + (size_t)pz * plane);
           }
           const int sa = (sload < g1 ? sload : g1 - 1) - g0;  // slot inside the resident group
 #pragma unroll
           for (int o = 0; o < NCO; ++o)
 #pragma unroll
-            for (int pz = 0; pz < NS; ++pz) ap[o][pz] = *(const bf8*)(wl + (((size_t)o * SG + sa) * 3 + pz) * 1024 + lane * 16);
+            for (int pz = 0; pz < NWP; ++pz) ap[o][pz] = *(const bf8*)(wl + (((size_t)o * SG + sa) * 3 + pz) * 1024 + lane * 16);
           ++sload; tl += 2; dx += 2;
           if (dx >= kw) { dx -= kw; ++dy; }
           if (dx >= kw) { dx -= kw; ++dy; }
         };
-        auto mma_slab = [&](const bf8 (&bp)[CBF_NU][NS], const bf8 (&ap)[NCO][NS]) {
+        auto mma_slab = [&](const bf8 (&bp)[CBF_NU][NS], const bf8 (&ap)[NCO][NWP]) {
 #pragma unroll
-          for (int o = 0; o < NCO; ++o) {
+          for (int o = 0; o < NCO; ++o)
 #pragma unroll
-            for (int u = 0; u < CBF_NU; ++u) {
-              f4 c = acc[o][u];
-              if (NS == 3) {
-                c = mfma_bf(ap[o][0], bp[u][2], c);
-                c = mfma_bf(ap[o][2], bp[u][0], c);
-                c = mfma_bf(ap[o][1], bp[u][1], c);
-                c = mfma_bf(ap[o][0], bp[u][1], c);
-                c = mfma_bf(ap[o][1], bp[u][0], c);
-              }
-              c = mfma_bf(ap[o][0], bp[u][0], c);
-              acc[o][u] = c;
-            }
-          }
+            for (int u = 0; u < CBF_NU; ++u) acc[o][u] = chain_bf<NS>(ap[o], bp[u], acc[o][u]);
         };
-        bf8 bA[CBF_NU][NS], aA[NCO][NS], bB[CBF_NU][NS], aB[NCO][NS];
+        bf8 bA[CBF_NU][NS], aA[NCO][NWP], bB[CBF_NU][NS], aB[NCO][NWP];
         for (;;) {
           const int ng = g1 - g0;
           load_slab(bA, aA);
@@ -1333,6 +1365,7 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
       }
       // store this batch row's tile
       const size_t nimg = (size_t)a.B * d->g_px_off[g] + (size_t)b * P;
+      const float inv = a.inv[br];
 #pragma unroll
       for (int o = 0; o < NCO; ++o) {
         if (co0 + o < nco_tot) {
@@ -1340,8 +1373,9 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
           for (int u = 0; u < CBF_NU; ++u) {
             if (u < nu && pok[u]) {
               const int ch = br * a.out_stride_br + 16 * (co0 + o);
-              if (a.out_p3) store_p3((__bf16*)a.out + ((nimg + oidx[u]) * (a.OUTC >> 4) + (ch >> 4)) * 48, lane >> 4, acc[o][u]);
-              else *(f4*)((float*)a.out + (nimg + oidx[u]) * a.OUTC + ch + 4 * (lane >> 4)) = acc[o][u];
+              const f4 v = NS == 2 ? acc[o][u] * inv : acc[o][u];
+              if (a.out_p3) store_px<NS == 2 ? 2 : 3>((__bf16*)a.out + ((nimg + oidx[u]) * (a.OUTC >> 4) + (ch >> 4)) * PXE, lane >> 4, v);
+              else *(f4*)((float*)a.out + (nimg + oidx[u]) * a.OUTC + ch + 4 * (lane >> 4)) = v;
             }
           }
         }
@@ -1799,11 +1833,11 @@ static WsLayout ws_layout(const FtnPlan* pl, int B, int L, int max_groups, int p
   w.c1 = pl->mode == 0 ? CA : pl->FP;                 // m / m'   (mode 1: conv1 output)
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   // stage A output: one row per window position (+ pad row), shared by all period groups
-  const int bpv = (pl->engine != 0 && pl->mode == 0) ? 6 : 4;                          // P3 = 6 bytes per value
+  const int bpv = (pl->engine == 0 || pl->engine == 3 || pl->mode != 0) ? 4 : 6;       // fp32 / H2: 4 bytes per value, P3: 6
   w.offA = FTN_WS_HEAD;
   w.off0 = al(w.offA + ((size_t)B * L + 1) * (pl->mode == 0 ? CA : pl->CP) * bpv);
-  w.off1 = al(w.off0 + N * w.c0 * (pl->engine != 0 && pl->mode == 0 ? 6 : 4));   // P3 = 6 bytes per value
-  w.off2 = al(w.off1 + N * w.c1 * (pl->engine != 0 && pl->mode == 0 ? 6 : 4));   // R [N][CP]
+  w.off1 = al(w.off0 + N * w.c0 * bpv);
+  w.off2 = al(w.off1 + N * w.c1 * bpv);               // R [N][CP]
   w.off3 = al(w.off2 + N * pl->CP * 4);               // G [N][FP] (mode 1)
   w.total = pl->mode == 0 ? w.off3 : al(w.off3 + N * pl->FP * 4);
   return w;
@@ -1868,11 +1902,12 @@ static int launch_conv(ConvArgs& ca, int B, int L, int grid_x, hipStream_t st) {
   return launch_conv_t<1>(ca, grid, lds, st);
 }
 
-struct ConvBfGeom { int NCO; size_t lds; int region_bytes, wbytes, sgroup; };
+struct ConvBfGeom { int NCO; size_t lds; int plane_bytes, region_bytes, wbytes, sgroup; };
 
-// LDS plan of the bf16x3 conv engine for window length L; NCO = 0 when it does not fit.
-static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int cout) {
-  ConvBfGeom gm = {0, 0, 0, 0, 0};
+// LDS plan of the split conv engines for window length L (npieces = activation piece planes per region:
+// 3 bf16x3, 2 f16x2, 1 plain bf16); NCO = 0 when it does not fit.
+static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int cout, int npieces) {
+  ConvBfGeom gm = {0, 0, 0, 0, 0, 0};
   int region_px = 1, smax = 1;
   for (int k = 0; k < nbr; ++k) {
     if (kh[k] > 31 || kw[k] > 31) return gm;
@@ -1881,10 +1916,11 @@ static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int
     int sl = (kh[k] * kw[k] + 1) / 2;
     if (sl > smax) smax = sl;
   }
-  gm.region_bytes = ((region_px * P3_LDS_STRIDE + 1023) & ~1023) + P3_LDS_STRIDE;
+  gm.plane_bytes = ((region_px * CBF_PX_BYTES + 1023) & ~1023) + 64;     // whole DMA pieces + the zero pixel
+  gm.region_bytes = npieces * gm.plane_bytes;
   const int nco_tot = cout / 16;
-  // Output tiles per workgroup: more tiles share every pixel fragment read (the kernel is LDS-read bound).  When
-  // all slabs' weights do not fit beside the two region buffers, they are staged in groups of `sgroup` slabs.
+  // Output tiles per workgroup: more tiles share every pixel fragment read.  When all slabs' weights do not fit
+  // beside the two region buffers, they are staged in groups of `sgroup` slabs.
   for (int nco = nco_tot >= 4 ? 4 : (nco_tot >= 2 ? 2 : 1); nco >= 1; nco >>= 1) {
     const size_t room = 160 * 1024 - 2 * (size_t)gm.region_bytes;
     int sg = (int)(room / ((size_t)nco * 3 * 1024));
@@ -1908,9 +1944,17 @@ static int launch_conv_bf_t(const ConvBfArgs& ca, dim3 grid, size_t lds, hipStre
   return 0;
 }
 
+template <int NS>
+static int launch_conv_bf_n(const ConvBfArgs& ca, const ConvBfGeom& gm, dim3 grid, hipStream_t st) {
+  if (gm.NCO == 4) return launch_conv_bf_t<4, NS>(ca, grid, gm.lds, st);
+  if (gm.NCO == 2) return launch_conv_bf_t<2, NS>(ca, grid, gm.lds, st);
+  return launch_conv_bf_t<1, NS>(ca, grid, gm.lds, st);
+}
+
 static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_x, int nsplit, hipStream_t st) {
   const int nco_tot = ca.cout / 16;
   ca.nchunk = ftn_cdiv(nco_tot, gm.NCO);
+  ca.plane_bytes = gm.plane_bytes;
   ca.region_bytes = gm.region_bytes;
   ca.wbytes = gm.wbytes;
   ca.sgroup = gm.sgroup;
@@ -1927,14 +1971,9 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
     ca.order[jj + 1] = v;
   }
   dim3 grid(grid_x, ftn_cdiv(B, ca.bpw), ca.nbr * ca.nchunk);
-  if (nsplit == 3) {
-    if (gm.NCO == 4) return launch_conv_bf_t<4, 3>(ca, grid, gm.lds, st);
-    if (gm.NCO == 2) return launch_conv_bf_t<2, 3>(ca, grid, gm.lds, st);
-    return launch_conv_bf_t<1, 3>(ca, grid, gm.lds, st);
-  }
-  if (gm.NCO == 4) return launch_conv_bf_t<4, 1>(ca, grid, gm.lds, st);
-  if (gm.NCO == 2) return launch_conv_bf_t<2, 1>(ca, grid, gm.lds, st);
-  return launch_conv_bf_t<1, 1>(ca, grid, gm.lds, st);
+  if (nsplit == 3) return launch_conv_bf_n<3>(ca, gm, grid, st);
+  if (nsplit == 2) return launch_conv_bf_n<2>(ca, gm, grid, st);
+  return launch_conv_bf_n<1>(ca, gm, grid, st);
 }
 
 template <int ACT, bool XIN, int EPI>
@@ -2038,15 +2077,19 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
   if (pl->mode == 0) {
     const int CA = pl->nbr * pl->MP;
     // conv engine: exact fp32 MFMA, or the bf16 matrix pipe (3 pieces = fp32-equivalent, 1 = plain bf16)
-    ConvBfGeom bfg = {0, 0, 0, 0, 0};
-    if (pl->engine != 0) bfg = conv_bf_geom(L, pl->nbr, pl->kh, pl->kw, pl->MP);
+    // activation pieces: 3 = bf16x3, 2 = f16x2, 1 = plain bf16
+    const int nsplit = pl->engine == 2 ? 1 : (pl->engine == 3 ? 2 : 3);
+    ConvBfGeom bfg = {0, 0, 0, 0, 0, 0};
+    if (pl->engine != 0) bfg = conv_bf_geom(L, pl->nbr, pl->kh, pl->kw, pl->MP, nsplit);
     const bool use_bf = pl->engine != 0 && bfg.NCO > 0;
-    const int nsplit = pl->engine == 2 ? 1 : 3;
+    const bool h2 = use_bf && pl->engine == 3;
+    // (a kernel set whose weights do not fit the split engines' LDS plan runs on the exact fp32 MFMA kernels)
     // A: a = W_in1 x + b
     PwArgs pa = {};
     pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = bufA; pa.desc = desc;
     pa.B = B; pa.L = L; pa.C = C; pa.KIN = CP; pa.n_ot = CA / 16; pa.OUTC = CA;
-    if (use_bf) { if ((rc = launch_pw<ACT, true, 2>(pa, xvec, nblk_pw, st))) return rc; }
+    if (use_bf && h2) { if ((rc = launch_pw<ACT, true, 3>(pa, xvec, nblk_pw, st))) return rc; }
+    else if (use_bf) { if ((rc = launch_pw<ACT, true, 2>(pa, xvec, nblk_pw, st))) return rc; }
     else if ((rc = launch_pw<ACT, true, 0>(pa, xvec, nblk_pw, st))) return rc;
     prof_mark(1, st);
     ConvBfArgs cb = {};
@@ -2059,10 +2102,13 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
                            pl->cfragbf_per_chunk == 28 &&
                            (size_t)28 * 3 * 1024 + (size_t)pl->n_hchunks * 32 * 2 * sizeof(float) <= 160 * 1024;
     if (use_bf) {
-      cb.in = (const __bf16*)bufA; cb.bt_L = L; cb.out = buf1; cb.out_p3 = (mlp_bf || mlp_bf128) ? 1 : 0; cb.bias = wb + pl->b_conv1; cb.desc = desc;
+      cb.in = (const __bf16*)bufA; cb.bt_L = L; cb.out = buf1; cb.out_p3 = (mlp_bf || mlp_bf128) ? 1 : 0; cb.bias = wb + (h2 ? pl->b_conv1s : pl->b_conv1); cb.desc = desc;
       cb.B = B; cb.INC = CA; cb.OUTC = CA; cb.nbr = pl->nbr; cb.cin = pl->MP; cb.cout = pl->MP;
       cb.in_stride_br = pl->MP / 16; cb.out_stride_br = pl->MP;
-      for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf1[k]); cb.kh[k] = pl->kh[k]; cb.kw[k] = pl->kw[k]; }
+      for (int k = 0; k < pl->nbr; ++k) {
+        cb.W[k] = (const __bf16*)(wb + pl->w_convbf1[k]); cb.kh[k] = pl->kh[k]; cb.kw[k] = pl->kw[k];
+        cb.inv[k] = h2 ? 1.0f / pl->sc_conv1[k] : 1.0f;
+      }
     }
     // B: m = conv(a)
     ConvArgs ca = {};
@@ -2081,13 +2127,16 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ma.nKM = CA / 16; ma.nCP = pl->res1 ? CP / 16 : 0;
     ma.n_hchunks = pl->n_hchunks; ma.cfrag_per_chunk = pl->cfrag_per_chunk;
     ma.n_oa = CA / 16; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = ma.n_oa + (pl->res2 ? CP / 16 : 0);
-    ma.outA_p3 = use_bf ? 1 : 0;
+    ma.outA_p3 = use_bf ? (h2 ? 2 : 1) : 0;
     if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model/mid too large for v1", ma.n_ot); return -1; }
     if (ma.cfrag_per_chunk != MLP_HT * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
     if (mlp_bf || mlp_bf128) {
       MlpBfArgs mb = {};
       mb.x = x; mb.m = (const __bf16*)buf1; mb.cfrag = (const __bf16*)(wb + pl->w_cfragbf);
-      mb.bo = wb + pl->b_out1; mb.br = wb + pl->b_res1; mb.bc = wb + pl->b_c2;
+      mb.bo = wb + (h2 ? pl->b_out1s : pl->b_out1); mb.br = wb + (h2 ? pl->b_res1s : pl->b_res1);
+      mb.bc = wb + (h2 ? pl->b_c2s : pl->b_c2);
+      mb.inv_o = h2 ? 1.0f / pl->sc_out1 : 1.0f; mb.sc_r = h2 ? pl->sc_res1 : 1.0f; mb.inv_r = h2 ? 1.0f / pl->sc_res1 : 1.0f;
+      mb.inv_a = h2 ? 1.0f / pl->sc_a2 : 1.0f; mb.inv_r2 = h2 ? 1.0f / pl->sc_r2 : 1.0f;
       mb.outA = (__bf16*)buf0; mb.outR = bufR; mb.desc = desc;
       mb.B = B; mb.L = L; mb.C = C; mb.CP = CP; mb.FP = FP; mb.KM = CA; mb.AC = CA;
       mb.nsKM = (CA + 31) / 32; mb.nsCP = (CP + 31) / 32;
@@ -2095,8 +2144,10 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
       if (mb.per_chunk != 2 * mb.nsKM + 2 * mb.nsCP + mb.n_ot) { ftn_set_error("plan/cfragbf layout mismatch"); return -1; }
       if (mlp_bf128) {
         if (nsplit == 3) { if ((rc = launch_mlp_bf_c128<ACT, 3>(mb, xvec, Nmax, st))) return rc; }
+        else if (nsplit == 2) { if ((rc = launch_mlp_bf_c128<ACT, 2>(mb, xvec, Nmax, st))) return rc; }
         else if ((rc = launch_mlp_bf_c128<ACT, 1>(mb, xvec, Nmax, st))) return rc;
       } else if (nsplit == 3) { if ((rc = launch_mlp_bf<ACT, 3>(mb, xvec, Nmax, st))) return rc; }
+      else if (nsplit == 2) { if ((rc = launch_mlp_bf<ACT, 2>(mb, xvec, Nmax, st))) return rc; }
       else if ((rc = launch_mlp_bf<ACT, 1>(mb, xvec, Nmax, st))) return rc;
     } else if ((rc = launch_mlp<ACT>(ma, xvec, Nmax, st))) return rc;
     prof_mark(3, st);
@@ -2104,8 +2155,8 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ca.in = buf0; ca.bt_L = 0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
     if (use_bf) {
-      cb.in = (const __bf16*)buf0; cb.bt_L = 0; cb.bias = wb + pl->b_conv2; cb.out_p3 = 0;
-      for (int k = 0; k < pl->nbr; ++k) cb.W[k] = (const __bf16*)(wb + pl->w_convbf2[k]);
+      cb.in = (const __bf16*)buf0; cb.bt_L = 0; cb.bias = wb + (h2 ? pl->b_conv2s : pl->b_conv2); cb.out_p3 = 0;
+      for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf2[k]); cb.inv[k] = h2 ? 1.0f / pl->sc_conv2[k] : 1.0f; }
       if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st))) return rc;
     } else if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(4, st);

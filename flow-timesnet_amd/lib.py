@@ -60,6 +60,10 @@ class FtnPlan(C.Structure):
         ("w_cfrag", C.c_int64), ("cfrag_per_chunk", C.c_int32), ("n_hchunks", C.c_int32),
         ("w_convbf1", C.c_int64 * FTN_MAXBR), ("w_convbf2", C.c_int64 * FTN_MAXBR),
         ("engine", C.c_int32), ("cfragbf_per_chunk", C.c_int32), ("w_cfragbf", C.c_int64),
+        ("b_conv1s", C.c_int64), ("b_conv2s", C.c_int64), ("b_out1s", C.c_int64), ("b_res1s", C.c_int64),
+        ("b_c2s", C.c_int64),
+        ("sc_conv1", C.c_float * FTN_MAXBR), ("sc_conv2", C.c_float * FTN_MAXBR),
+        ("sc_out1", C.c_float), ("sc_res1", C.c_float), ("sc_a2", C.c_float), ("sc_r2", C.c_float),
         ("total_floats", C.c_int64),
     ]
 

@@ -107,6 +107,91 @@ def _pack_conv_bf(w: np.ndarray, cinP: int, coutP: int) -> np.ndarray:
     return _bf16_bits_as_f32(out)
 
 
+# ---- f16x2 engine: three fp16 weight pieces of the power-of-two-prescaled matrix (csrc/ftn_common.h) ----
+H2_LOSHIFT = 11          # activations: lo' = (x - fp16(x)) * 2^11; weights: A2 = fp16(A1 * 2^-11)
+
+
+def pow2_scale(W: np.ndarray) -> float:
+    """Power of two ``sc`` with ``max|sc W|`` in [2^10, 2^11): the three fp16 pieces of ``sc W`` - including
+    ``A2 = A1 2^-11`` and the remainder ``A3 ~ 2^-11 |sc W|`` - then stay fp16 normals for every weight that is
+    not negligible beside the largest one, and fp16 cannot overflow (max 65504)."""
+    m = float(np.max(np.abs(W))) if W.size else 0.0
+    if not np.isfinite(m) or m <= 0.0:
+        return 1.0
+    return float(2.0 ** (10 - int(np.floor(np.log2(m)))))
+
+
+def split_h2_weights(Ws: np.ndarray):
+    """(A1, A2, A3) fp16 pieces (held as fp32) of an already prescaled weight array."""
+    Ws = np.asarray(Ws, dtype=np.float32)
+    a1 = Ws.astype(np.float16)
+    a2 = (a1.astype(np.float32) * np.float32(2.0 ** -H2_LOSHIFT)).astype(np.float16)
+    a3 = (Ws - a1.astype(np.float32)).astype(np.float16)
+    return a1, a2, a3
+
+
+def split_h2_act(x: np.ndarray):
+    """(hi, lo') fp16 pieces of activations, as csrc/ftn_common.h split_h2 (round to nearest even)."""
+    x = np.asarray(x, dtype=np.float32)
+    hi = x.astype(np.float16)
+    lo = ((x - hi.astype(np.float32)) * np.float32(2.0 ** H2_LOSHIFT)).astype(np.float16)
+    return hi, lo
+
+
+def _f16_bits_as_f32(pieces: np.ndarray) -> np.ndarray:
+    """fp16 array -> its 16-bit patterns packed two per float32 word."""
+    flat = np.ascontiguousarray(pieces, dtype=np.float16).view(np.uint16).reshape(-1)
+    if flat.size % 2:
+        flat = np.concatenate([flat, np.zeros(1, np.uint16)])
+    return flat.view(np.float32)
+
+
+def _pack_conv_h2(w: np.ndarray, cinP: int, coutP: int, sc: float) -> np.ndarray:
+    """As ``_pack_conv_bf`` with the f16x2 pieces of ``sc * w``: [cc][co][slab][piece][lane][8]."""
+    cout, cin, kh, kw = w.shape
+    nt = kh * kw
+    S = (nt + 1) // 2
+    wp = np.zeros((coutP, cinP, 2 * S), np.float32)
+    wp[:cout, :cin, :nt] = (np.asarray(w, np.float64) * sc).reshape(cout, cin, nt)
+    v = wp.reshape(coutP // 16, 16, cinP // 16, 2, 8, S, 2)          # [co][i][cc][half][e][slab][tp]
+    v = v.transpose(2, 0, 5, 6, 3, 1, 4)                                # [cc][co][slab][tp][half][i][e]
+    v = np.ascontiguousarray(v).reshape(cinP // 16, coutP // 16, S, 4, 16, 8)   # qa = 2*tp + half
+    a1, a2, a3 = split_h2_weights(v)
+    return _f16_bits_as_f32(np.stack([a1, a2, a3], axis=3))           # [cc][co][slab][piece][qa][i][e]
+
+
+def _frag_h2(W, R: int, cols) -> np.ndarray:
+    """K=32 fp16 A fragment of the (prescaled) matrix W, three pieces: [piece][qa][i][e] (cf. ``_frag_bf``)."""
+    blk = np.zeros((16, 32), np.float32)
+    if W is not None:
+        r0 = 16 * R
+        rows = min(16, max(0, W.shape[0] - r0))
+        for k, c in enumerate(cols):
+            if c >= 0 and c < W.shape[1] and rows > 0:
+                blk[:rows, k] = W[r0:r0 + rows, c]
+    lanes = blk.reshape(16, 4, 8).transpose(1, 0, 2)              # [qa][i][e]
+    return np.stack(split_h2_weights(lanes), axis=0)
+
+
+def _pack_cfrag_h2(W_out, W_res, W_c, FP: int, nsKM: int, nsCP: int, n_ot: int) -> np.ndarray:
+    """``_pack_cfrag_bf`` for the f16x2 engine; the matrices arrive prescaled."""
+    nch = (FP + 31) // 32
+    per = 2 * nsKM + 2 * nsCP + n_ot
+    out = np.zeros((nch, max(per, 1), 3, 4, 16, 8), np.float16)
+    for hc in range(nch):
+        k = 0
+        for t in range(2):
+            for s_ in range(nsKM):
+                out[hc, k] = _frag_h2(W_out, hc * 2 + t, list(range(32 * s_, 32 * s_ + 32))); k += 1
+        for t in range(2):
+            for s_ in range(nsCP):
+                out[hc, k] = _frag_h2(W_res, hc * 2 + t, list(range(32 * s_, 32 * s_ + 32))); k += 1
+        perm = [32 * hc + (4 * qa + e if e < 4 else 16 + 4 * qa + e - 4) for qa in range(4) for e in range(8)]
+        for o in range(n_ot):
+            out[hc, k] = _frag_h2(W_c, o, perm); k += 1
+    return _f16_bits_as_f32(out)
+
+
 def _frag(W: np.ndarray, R: int, S: int) -> np.ndarray:
     """16x16 block (rows 16R.., cols 16S..) of W as a lane-linear MFMA A fragment:
     [lane = 16*q + j][e] = W[16R + j][16S + 4q + e]; zero outside W."""
@@ -184,16 +269,19 @@ def _check_odd(ks):
             raise ValueError(f"kernel sizes must be odd and positive for 'same' padding, got {(kh, kw)}")
 
 
-ENGINES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+ENGINES = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x2": 3}
+DEFAULT_ENGINE = "f16x2"
 
 
 def default_engine() -> str:
-    """Conv arithmetic: ``f32`` exact fp32 MFMA; ``bf16x3`` three-piece bf16 split on the bf16
-    matrix pipe (fp32-equivalent accuracy, 2.7x fewer MFMA cycles); ``bf16`` plain bf16
-    operands with fp32 accumulation (BASELINE configs[2]).  Env ``FLOWTIMES_ENGINE``."""
+    """Conv arithmetic: ``f32`` exact fp32 MFMA; ``f16x2`` (default) two fp16 pieces per activation and three
+    per (prescaled) weight, three products per fp32 multiply on the fp16 matrix pipe - fp32-equivalent accuracy
+    (2^-22 per operand) for activations below the fp16 maximum 65504, the range the reference's own fp16-autocast
+    GPU path assumes; ``bf16x3`` three bf16 pieces, six products, the full fp32 exponent range; ``bf16`` plain
+    bf16 operands with fp32 accumulation (BASELINE configs[2]).  Env ``FLOWTIMES_ENGINE``."""
     import os
 
-    e = os.environ.get("FLOWTIMES_ENGINE", "bf16x3").strip().lower()
+    e = os.environ.get("FLOWTIMES_ENGINE", DEFAULT_ENGINE).strip().lower()
     if e not in ENGINES:
         raise ValueError(f"FLOWTIMES_ENGINE must be one of {sorted(ENGINES)}, got {e!r}")
     return e
@@ -240,6 +328,8 @@ def pack_inception(
         CA = nk * MP
 
         convs_bf = []
+        h2 = plan.engine == ENGINES["f16x2"]
+        conv_sc = []
 
         def block(blk, cin, cout, cinP, coutP):
             W_in = np.zeros((CA, cinP)); b_in = np.zeros(CA)
@@ -261,7 +351,9 @@ def pack_inception(
                 W_out[:cout, j * MP: j * MP + mid] = Pk @ w3
                 b_out[:cout] += Pk @ sd[f"{blk}.paths.{j}.branch.2.bias"]
                 convs.append(_pack_conv(w2, MP, MP))
-                convs_bf.append(_pack_conv_bf(w2, MP, MP))
+                sc = pow2_scale(w2) if h2 else 1.0
+                conv_sc.append(sc)
+                convs_bf.append(_pack_conv_h2(w2, MP, MP, sc) if h2 else _pack_conv_bf(w2, MP, MP))
             return W_in, b_in, convs, b_conv, W_out, b_out
 
         W_in1, b_in1, convs1, b_conv1, W_out1, b_out1 = block("0", C, F, CP, FP)
@@ -302,10 +394,31 @@ def pack_inception(
         for j in range(nk):
             plan.w_convbf1[j] = blob.add(convs_bf[j])
             plan.w_convbf2[j] = blob.add(convs_bf[nk + j])
+        for j in range(FTN_MAXBR):
+            plan.sc_conv1[j] = plan.sc_conv2[j] = 1.0
+        plan.sc_out1 = plan.sc_res1 = plan.sc_a2 = plan.sc_r2 = 1.0
+        if h2:
+            # biases prescaled like their weight matrices: the accumulators start from them (flowtimes.h FtnPlan)
+            s1 = np.repeat(np.array(conv_sc[:nk]), MP)
+            s2 = np.repeat(np.array(conv_sc[nk:]), MP)
+            for j in range(nk):
+                plan.sc_conv1[j], plan.sc_conv2[j] = conv_sc[j], conv_sc[nk + j]
+            plan.b_conv1s, plan.b_conv2s = blob.add(b_conv1 * s1), blob.add(b_conv2 * s2)
         if plan.res1 and plan.res2:
             nsKM, nsCP = (CA + 31) // 32, (CP + 31) // 32
-            plan.w_cfragbf = blob.add(_pack_cfrag_bf(W_out1.astype(np.float32), Wr1.astype(np.float32),
-                                                     Wc.astype(np.float32), FP, nsKM, nsCP, n_ot))
+            if h2:
+                plan.sc_out1, plan.sc_res1 = pow2_scale(W_out1), pow2_scale(Wr1)
+                plan.sc_a2, plan.sc_r2 = pow2_scale(W_in2), pow2_scale(Wr2)
+                Wcs = np.concatenate([W_in2 * plan.sc_a2, Wr2 * plan.sc_r2], 0)
+                plan.b_out1s, plan.b_res1s = blob.add(b_out1 * plan.sc_out1), blob.add(np.concatenate(
+                    [sd["0.res_proj.bias"], np.zeros(FP - F)]) * plan.sc_res1)
+                plan.b_c2s = blob.add(np.concatenate([b_in2 * plan.sc_a2, br2 * plan.sc_r2], 0))
+                plan.w_cfragbf = blob.add(_pack_cfrag_h2((W_out1 * plan.sc_out1).astype(np.float32),
+                                                         (Wr1 * plan.sc_res1).astype(np.float32),
+                                                         Wcs.astype(np.float32), FP, nsKM, nsCP, n_ot))
+            else:
+                plan.w_cfragbf = blob.add(_pack_cfrag_bf(W_out1.astype(np.float32), Wr1.astype(np.float32),
+                                                         Wc.astype(np.float32), FP, nsKM, nsCP, n_ot))
             plan.cfragbf_per_chunk = 2 * nsKM + 2 * nsCP + n_ot
     else:
         plan.mode = 1

@@ -86,7 +86,8 @@ typedef struct FtnPlan {
   int32_t n_hchunks;        /* ceil(FP / 32)                               */
   /* bf16x3 conv engine (mode 0 only): per branch the k x k weights as three bf16 pieces in
    * K=32 MFMA fragments, [cin/16][cout/16][slab = tap pair][piece][lane][8] (offsets in
-   * floats; the data are bf16).  engine: 0 = exact fp32 MFMA, 1 = bf16x3 split, 2 = plain bf16 */
+   * floats; the data are bf16).  engine: 0 = exact fp32 MFMA, 1 = bf16x3 split, 2 = plain bf16,
+   * 3 = f16x2 split (below) */
   int64_t w_convbf1[FTN_MAXBR];
   int64_t w_convbf2[FTN_MAXBR];
   int32_t engine;
@@ -94,6 +95,14 @@ typedef struct FtnPlan {
    * res_proj convs exist): [chunk][w_out1 2 x ceil(KM/32) | w_res1 2 x ceil(CP/32) | w_c n_ot][piece] */
   int32_t cfragbf_per_chunk;
   int64_t w_cfragbf;
+  /* f16x2 engine (engine 3; mode 0 only): w_convbf1/2 and w_cfragbf then hold THREE fp16 pieces per weight
+   * fragment - A1 = fp16(W~), A2 = fp16(A1 2^-11), A3 = fp16(W~ - A1) of the prescaled matrix W~ = sc W with
+   * sc a power of two (per conv branch, per stage-C matrix) - and activations travel as two fp16 pieces
+   * (hi, (x - hi) 2^11).  The kernels start their accumulators from biases prescaled by the same sc (offsets
+   * below) and multiply by 1/sc when they leave the matrix pipe. */
+  int64_t b_conv1s, b_conv2s, b_out1s, b_res1s, b_c2s;
+  float sc_conv1[FTN_MAXBR], sc_conv2[FTN_MAXBR];
+  float sc_out1, sc_res1, sc_a2, sc_r2;   /* W_out1, W_res1, W_in2 rows of w_c2, W_res2 rows of w_c2 */
   int64_t total_floats;
 } FtnPlan;
 

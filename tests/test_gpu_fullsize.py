@@ -63,7 +63,7 @@ def test_c1_full_size_fp32_engine(ftn, dev):
     _full_size_block_properties(ftn, dev, 256, 336, 64, 3, "f32", [24, 168, 7], [0, 17, 128, 255])
 
 
-@pytest.mark.parametrize("engine", ["bf16x3", "f32"])
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3", "f32"])
 def test_c3_full_size_block(engine, ftn, dev):
     """BASELINE configs[3] (one GPU's TimesBlock): B=256 L=720 d_model=128 d_ff=512 k=5 - 0.95 M grid pixels,
     the flat pixel index and the 1.8 GB workspace at their real sizes."""

@@ -33,7 +33,7 @@ def _hyper(case):
     return C, d_ff, [tuple(k) for k in h["kernel_set"]], h["ratio"], h["act"], h["d_ff_mult"] is None
 
 
-ENGINES = ["f32", "bf16x3"]
+ENGINES = ["f32", "bf16x3", "f16x2"]
 
 
 def _block(ftn, case, dev, engine=None):
@@ -209,12 +209,13 @@ def test_engines_agree_and_plain_bf16_is_close(ftn, dev):
     case = dict(hyper="pipeline", C=64, seed=4)
     x = torch.from_numpy(ftn.synth.make_input(8, 336, 64, seed=4)).to(dev)
     ys = {}
-    for eng in ("f32", "bf16x3", "bf16"):
+    for eng in ("f32", "bf16x3", "f16x2", "bf16"):
         blk, _, _, _ = _block(ftn, case, dev, eng)
         blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(5, 336)
         with torch.inference_mode():
             ys[eng] = blk(x).cpu().numpy()
     np.testing.assert_allclose(ys["bf16x3"], ys["f32"], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(ys["f16x2"], ys["f32"], rtol=2e-5, atol=5e-6)
     np.testing.assert_allclose(ys["bf16"], ys["f32"], rtol=5e-2, atol=5e-2)
     assert np.abs(ys["bf16"] - ys["f32"]).max() > 1e-5          # it really is a different arithmetic
 

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(ftn):
 def test_struct_sizes_match_header(ftn):
     # FtnDesc: 4 + 6*16 + 17 + 4*16 + 17 ints ; FtnPlan: 26 ints + 33 int64 + 2 ints + 1 int64
     assert ctypes.sizeof(ftn.lib.FtnDesc) == 4 * (4 + 6 * 16 + 17 + 4 * 16 + 17)
-    assert ctypes.sizeof(ftn.lib.FtnPlan) == 4 * 26 + 8 * 33 + 4 * 2 + 8 * 16 + 4 * 2 + 8 + 8
+    assert ctypes.sizeof(ftn.lib.FtnPlan) == 4 * 26 + 8 * 33 + 4 * 2 + 8 * 16 + 4 * 2 + 8 + 8 * 5 + 4 * 20 + 8
 
 
 @pytest.mark.parametrize("periods,L", [([24, 168, 7, 24, 0, 500], 336), ([4, 4, 8, 4], 25), ([47, 24, 2], 48),
@@ -78,6 +78,29 @@ def test_packed_weights_reproduce_reference(name, manifest, golden, ftn):
     w = orc.group_weights(amps, grp.mapping, len(grp.periods)).numpy()
     y = emu.emulate(g["x"], blob, plan, grp.periods, w)
     np.testing.assert_allclose(y, g["y"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["b_tiny_pipe", "b_c0_pipe", "b_c0_rect", "b_odd_pipe", "s_wide_rows", "s_448", "b_noise_pipe"])
+def test_f16x2_packed_pieces_reproduce_reference(name, manifest, golden, ftn):
+    """The f16x2 engine on the CPU: the packed fp16 weight pieces (three per prescaled fragment), two-piece
+    activations, prescaled biases and scales replayed in numpy must give the reference's outputs - this pins
+    the packing layout, the scale bookkeeping and the scheme's accuracy without a GPU."""
+    case, g = manifest[name], golden(name)
+    C, d_ff, ks, ratio, act = _hyper(case)
+    sd = ftn.synth.make_inception_params(C, d_ff, ks, ratio, case["seed"])
+    blob, plan = ftn.pack.pack_inception(sd, C, d_ff, ks, ratio, act, "f16x2")
+    assert plan.engine == 3 and blob.size == plan.total_floats
+    for sc in list(plan.sc_conv1)[:plan.nbr] + [plan.sc_out1, plan.sc_res1, plan.sc_a2, plan.sc_r2]:
+        assert sc > 0 and float(np.log2(sc)).is_integer()                 # powers of two: prescaling is exact
+    periods, amps = g["periods"].tolist(), torch.from_numpy(g["amps"])
+    if amps.shape[0] == 1:
+        amps = amps.expand(case["B"], -1)
+    grp = orc.period_group(periods, case["L"], 1, case["L"])
+    w = orc.group_weights(amps, grp.mapping, len(grp.periods)).numpy()
+    y = emu.emulate_h2(g["x"], blob, plan, grp.periods, w)
+    np.testing.assert_allclose(y, g["y"], rtol=1e-4, atol=2e-5)
+    y64 = emu.emulate(g["x"], *ftn.pack.pack_inception(sd, C, d_ff, ks, ratio, act, "f32"), grp.periods, w)
+    assert np.abs(y - y64).max() < 2e-6 * max(1.0, np.abs(y64).max())     # the split itself: fp32-level error
 
 
 @pytest.mark.parametrize("hyper,C", [("pipeline", 16), ("pipeline", 24), ("rect", 16), ("minimal", 16), ("wide1", 8)])
