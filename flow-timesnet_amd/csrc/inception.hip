@@ -36,6 +36,8 @@
 static unsigned long long* g_stamp_buf = nullptr;
 static size_t g_stamp_cap = 0;
 static int g_stamp_which = 0;  // 1: k_conv, 2: k_mlp
+static const bool g_conv_generic = [] { const char* e = getenv("FTN_CONV_GENERIC"); return e != nullptr && e[0] == '1'; }();  // experiment switch
+static const bool g_mlp_u1 = [] { const char* e = getenv("FTN_MLP_U1"); return e != nullptr && e[0] == '1'; }();   // experiment switch
 __device__ __forceinline__ void stamp(unsigned long long* buf, size_t cap, size_t wg, int slot) {
   if (buf != nullptr && threadIdx.x == 0 && (wg * 8 + slot) < cap) buf[wg * 8 + slot] = __builtin_amdgcn_s_memtime();
 }
@@ -480,26 +482,27 @@ struct MlpBfArgs {
 
 template <int NS>
 __device__ __forceinline__ f4 chain_bf(const bf8 (&ap)[PxFmt<NS>::NW], const bf8 (&bp)[NS], f4 c) {
-  if (NS == 3) {
+  if constexpr (NS == 3) {
     c = mfma_bf(ap[0], bp[2], c);
     c = mfma_bf(ap[2], bp[0], c);
     c = mfma_bf(ap[1], bp[1], c);
     c = mfma_bf(ap[0], bp[1], c);
     c = mfma_bf(ap[1], bp[0], c);
-  }
-  if (NS == 2) {                       // f16x2: A2 lo' + A3 hi + A1 hi (ftn_common.h), small terms first
+    return mfma_bf(ap[0], bp[0], c);
+  } else if constexpr (NS == 2) {      // f16x2: A2 lo' + A3 hi + A1 hi (ftn_common.h), small terms first
     c = mfma_h(ap[1], bp[1], c);
     c = mfma_h(ap[2], bp[0], c);
     return mfma_h(ap[0], bp[0], c);
+  } else {
+    return mfma_bf(ap[0], bp[0], c);
   }
-  return mfma_bf(ap[0], bp[0], c);
 }
 
 // eight fp32 values -> NS pieces of 8 (bf16: exact truncation split; fp16: hi + scaled remainder, ftn_common.h)
 template <int NS>
 __device__ __forceinline__ void split_pieces(const float (&v)[8], bf8 (&out)[NS]) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  if (NS == 2) {
+  if constexpr (NS == 2) {
     unsigned pc[2][4];
     split_h2<8>(v, pc);
 #pragma unroll
@@ -719,12 +722,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
     if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 7);
     if (hc == 1 && a.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(a.dbg, a.dbg_cap, blockIdx.x, 5); }
     __syncthreads();
+    if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 4);
     if (NBUF == 1 && hc + 1 < a.n_hchunks) {
       // single buffer: refill once every wave has left the chunk.  (Refilling in halves behind a
       // mid-chunk barrier hides the DMA but costs more in barrier skew than it saves: measured +5 %.)
       dma_chunk(hc + 1, 0);
       __syncthreads();
     }
+    if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 6);
   }
   stamp(a.dbg, a.dbg_cap, blockIdx.x, 3);
   if (!active) return;
@@ -755,9 +760,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
 // the 28 fragments of a chunk (84 KB) live in a single LDS buffer.  A fragment then feeds 6 MFMAs instead of
 // 12 - which lands on the LDS read rate (tools/ubench/lds_patterns.hip) at about the time the SIMD needs
 // for MFMA + GELU anyway.  The chunk is walked as one unrolled fragment sequence with a one-ahead prefetch.
-template <int ACT, bool XVEC, int NS>
-__global__ __launch_bounds__(512, 2) void k_mlp_bf_c128(MlpBfArgs a) {
-  constexpr int SKM = 3, SCP = 4, OTM = 14, NFR = 2 * SKM + 2 * SCP + OTM;
+// SKM / SCP = K=32 slabs of layer 1 / of the residual, OTM = output tiles: <3, 4, 14> is that shape; <2, 2, 7> is
+// d_model 64 with three kernels of mid 16 (48 -> 64 K padding), where the smaller register footprint lets two
+// 8-wave workgroups = four waves per SIMD share a CU (the two-unit k_mlp_bf above runs two).
+template <int ACT, bool XVEC, int NS, int SKM, int SCP, int OTM>
+__global__ __launch_bounds__(512, 2) void k_mlp_bf_u1(MlpBfArgs a) {
+  constexpr int NFR = 2 * SKM + 2 * SCP + OTM;
   extern __shared__ __attribute__((aligned(16))) char wlb[];
   const FtnDesc* __restrict__ d = a.desc;
   const int N = a.B * d->total_px;
@@ -880,18 +888,23 @@ __global__ __launch_bounds__(512, 2) void k_mlp_bf_c128(MlpBfArgs a) {
   }
 }
 
-template <int ACT, int NS>
-static int launch_mlp_bf_c128(MlpBfArgs ma, bool xvec, long long Nmax, hipStream_t st) {
+template <int ACT, int NS, int SKM, int SCP, int OTM>
+static int launch_mlp_bf_u1(MlpBfArgs ma, bool xvec, long long Nmax, hipStream_t st) {
   ma.dbg = nullptr; ma.dbg_cap = 0;
   const size_t lds = (size_t)ma.per_chunk * 3 * 1024 + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
   const int nblk = (int)((Nmax + 127) / 128);
-  hipError_t e = xvec ? hipFuncSetAttribute((const void*)k_mlp_bf_c128<ACT, true, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                      : hipFuncSetAttribute((const void*)k_mlp_bf_c128<ACT, false, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_bf_c128): %s", hipGetErrorString(e)); return (int)e; }
-  if (xvec) hipLaunchKernelGGL((k_mlp_bf_c128<ACT, true, NS>), dim3(nblk), dim3(512), lds, st, ma);
-  else hipLaunchKernelGGL((k_mlp_bf_c128<ACT, false, NS>), dim3(nblk), dim3(512), lds, st, ma);
+  hipError_t e = xvec ? hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                      : hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_bf_u1): %s", hipGetErrorString(e)); return (int)e; }
+  if (xvec) hipLaunchKernelGGL((k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM>), dim3(nblk), dim3(512), lds, st, ma);
+  else hipLaunchKernelGGL((k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM>), dim3(nblk), dim3(512), lds, st, ma);
   FTN_CHECK_LAUNCH();
   return 0;
+}
+
+template <int ACT, int NS>
+static int launch_mlp_bf_c128(const MlpBfArgs& ma, bool xvec, long long Nmax, hipStream_t st) {
+  return launch_mlp_bf_u1<ACT, NS, 3, 4, 14>(ma, xvec, Nmax, st);
 }
 
 // ---------------------------------------------------------------- stages B / D
@@ -1384,6 +1397,214 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
   }
   stamp(a.dbg, a.dbg_cap, wgid, 3);
   if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) a.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ---------------------------------------------------------------- stages B / D, split engines, fast path
+// The same convolution for the common geometry - one 16-channel input group and one output tile per branch
+// (mid <= 16), kernel 3x3 / 5x5 / 7x7, all slabs' weight fragments resident in LDS - with the tap walk resolved
+// at compile time.  In k_conv_bf every slab costs ~45 VALU instructions per wave (per-lane tap counters, two
+// shifts + a compare + a select per pixel unit, a 32-bit multiply for the row offset, address adds per piece)
+// for 9 MFMAs, and VALU issue, not the matrix pipe, sets its pace (PMC: 7.3 VALU per MFMA).  Here
+//   * the slab loop is fully unrolled over the kernel's taps, so each lane half's (dy, dx) is a constant and
+//     its LDS offset (dy*RW + dx)*32 two scalar operations;
+//   * the per-pixel tap validity (conv zero padding at the grid border) is one bit per slab in a mask built
+//     once per tile: bit s of vmask[u] = tap 2s + (lane half) is inside the grid for this lane's pixel;
+//   * the region planes sit CBF_FAST_PLANE bytes apart (a constant), so the second piece is a ds_read offset.
+// That leaves ~10 VALU per slab: v_bfe, v_add, v_mad per pixel unit and one select for the tap offset.
+#define CBF_FAST_PLANE (FTN_REGION_PX * CBF_PX_BYTES + 64)
+
+template <int NS, int KH, int KW>
+__device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __restrict__ reg, const char* __restrict__ wlane,
+                                               const int (&ld)[CBF_NU], const unsigned (&vmask)[CBF_NU], int zoffv,
+                                               int RW32, bool half1) {
+  constexpr int NWP = PxFmt<NS>::NW;
+  constexpr int NT = KH * KW, S = (NT + 1) / 2;
+  bf8 bA[CBF_NU][NS], aA[NWP], bB[CBF_NU][NS], aB[NWP];
+  auto load_slab = [&](int s, bf8 (&bp)[CBF_NU][NS], bf8 (&ap)[NWP]) {
+    // taps 2s (lanes 0-31) and 2s+1 (lanes 32-63); a tap index == NT (odd tap count) is masked off by vmask
+    const int t0 = 2 * s, t1 = 2 * s + 1 < NT ? 2 * s + 1 : 2 * s;
+    const int c0 = (t0 / KW) * RW32 + (t0 % KW) * CBF_PX_BYTES;
+    const int c1 = (t1 / KW) * RW32 + (t1 % KW) * CBF_PX_BYTES;
+    const int toff = half1 ? c1 : c0;
+    // weights first: the slab's first MFMA needs them, and LDS reads return in issue order
+#pragma unroll
+    for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(wlane + (s * 3 + pz) * 1024);
+#pragma unroll
+    for (int u = 0; u < CBF_NU; ++u) {
+      const int v = (int)__builtin_amdgcn_ubfe(vmask[u], (unsigned)s, 1u);
+      const int addr = __mul24(v, ld[u] + toff) + zoffv;          // valid ? pixel + tap : zero pixel
+#pragma unroll
+      for (int pz = 0; pz < NS; ++pz) bp[u][pz] = *(const bf8*)(reg + addr + pz * CBF_FAST_PLANE);
+    }
+  };
+  auto mma_slab = [&](const bf8 (&bp)[CBF_NU][NS], const bf8 (&ap)[NWP]) {
+#pragma unroll
+    for (int u = 0; u < CBF_NU; ++u) acc[u] = chain_bf<NS>(ap, bp[u], acc[u]);
+  };
+  // One scheduling region per slab: the LDS reads of slab s+1 interleaved one-for-one with the MFMAs of slab s
+  // (sched_group_barrier), so a read batch is never waited for right after its issue: with the reads fenced off
+  // behind a sched_barrier hipcc waited lgkmcnt(0) before every other MFMA group, i.e. half of the LDS latency
+  // was exposed (the 4-bit lgkmcnt cannot express "all but the 18 newest").
+  auto interleave = [&]() {
+    static_assert(CBF_NU == 3, "interleave patterns are written for three pixel units per wave");
+    if constexpr (NS == 2) {                                  // 9 reads : 9 MFMAs
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {                           // MFMA first: the wait in front of it then covers
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // only reads issued a whole slab earlier
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    } else if constexpr (NS == 3) {                           // 12 reads : 18 MFMAs
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    } else {                                                  // 4 reads : 3 MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+  };
+  load_slab(0, bA, aA);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < S; s += 2) {
+    if (s + 1 < S) load_slab(s + 1, bB, aB);
+    mma_slab(bA, aA);
+    if (s + 1 < S) interleave();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < S) {
+      if (s + 2 < S) load_slab(s + 2, bA, aA);
+      mma_slab(bB, aB);
+      if (s + 2 < S) interleave();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  constexpr int PXE = PxFmt<NS>::ELEMS;
+  constexpr int plane = CBF_FAST_PLANE;
+  const FtnDesc* __restrict__ d = a.desc;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int br = a.order[blockIdx.z];
+  const int kh = a.kh[br], kw = a.kw[br], hy = kh >> 1, hx = kw >> 1, ntaps = kh * kw;
+  const int S = (ntaps + 1) >> 1;
+  char* __restrict__ wl = ldsb;
+  char* __restrict__ rbuf0 = ldsb + a.wbytes;
+  const int zoff = plane - 64 + (qa & 1) * 16;               // zero pixel at the end of every plane
+  const int b_begin = blockIdx.y * a.bpw, b_end = min(a.B, b_begin + a.bpw);
+  const int G = d->n_groups, tiles_total = d->tiles_per_row;
+  if (threadIdx.x < 2 * NS * 4) {
+    const int pl = threadIdx.x >> 2;
+    *(f4*)(rbuf0 + (size_t)(pl / NS) * a.region_bytes + (size_t)(pl % NS) * plane + plane - 64 + (threadIdx.x & 3) * 16) = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int bx = blockIdx.x; bx < tiles_total; bx += gridDim.x) {
+    int g = 0;
+    for (int gg = 1; gg < G; ++gg)
+      if (bx >= d->g_tile_off[gg]) g = gg;
+    const int tix = bx - d->g_tile_off[g];
+    const int ntx = d->g_ntx[g];
+    const int ty = tix / ntx, tx = tix - ty * ntx;
+    const int p = d->g_period[g], cycles = d->g_cycles[g];
+    const int P = d->g_px_off[g + 1] - d->g_px_off[g];
+    const int r0 = ty * d->g_th[g], c0 = tx * d->g_tw[g];
+    const int th = min(d->g_th[g], cycles - r0), tw = min(d->g_tw[g], p - c0);
+    const int R0 = max(0, r0 - hy), R1 = min(cycles, r0 + th + hy);
+    const int C0 = max(0, c0 - hx), C1 = min(p, c0 + tw + hx);
+    const int RW = C1 - C0, RH = R1 - R0;
+    const int npx = th * tw, nunits = (npx + 15) >> 4;
+    const int in_groups = a.INC >> 4;
+    const float inv_tw = 1.0f / (float)tw, inv_rw = 1.0f / (float)RW;
+    const int nchunks16 = RH * RW * 2;
+    const int ppp = (nchunks16 + 63) >> 6;
+    const int btL = a.bt_L;
+    auto dma_region = [&](int b, int buf) {
+      const __bf16* __restrict__ src = a.in + (btL > 0 ? (size_t)b * btL : (size_t)a.B * d->g_px_off[g] + (size_t)b * P) * in_groups * PXE +
+                                       (size_t)(br * a.in_stride_br) * PXE;
+      const __bf16* __restrict__ src_pad = a.in + (size_t)a.B * btL * in_groups * PXE + (size_t)(br * a.in_stride_br) * PXE;
+      for (int pc = wv; pc < NS * ppp; pc += 8) {
+        const int pz = pc / ppp, pi = pc - pz * ppp;
+        int ci = pi * 64 + lane;
+        if (ci >= nchunks16) ci = nchunks16 - 1;
+        const int sp = ci >> 1, half = ci & 1;
+        const int rr = (int)(((float)sp + 0.5f) * inv_rw), cx = sp - rr * RW;
+        const int tpx = (R0 + rr) * p + C0 + cx;
+        const __bf16* __restrict__ row = (btL > 0 && tpx >= btL) ? src_pad : src + (size_t)tpx * in_groups * PXE;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(row + pz * 16 + half * 8),
+            (__attribute__((address_space(3))) void*)(rbuf0 + (size_t)buf * a.region_bytes + (size_t)pz * plane + (size_t)pi * 1024), 16, 0, 0);
+      }
+    };
+    // per-lane pixel bookkeeping, once per tile
+    const int wrot = (wave + (int)blockIdx.y) & 7;
+    const int nu = nunits > wrot ? (nunits - wrot + 7) >> 3 : 0;
+    const int h1 = qa >> 1;                                   // this lane's tap of every pair
+    int ld[CBF_NU], oidx[CBF_NU];
+    unsigned vmask[CBF_NU];
+    bool pok[CBF_NU];
+#pragma unroll
+    for (int u = 0; u < CBF_NU; ++u) {
+      int idx = (wrot + 8 * u) * 16 + j;
+      pok[u] = idx < npx;
+      if (!pok[u]) idx = 0;
+      const int r = (int)(((float)idx + 0.5f) * inv_tw), c = idx - r * tw;
+      const int ri = r0 + r, ci = c0 + c;
+      ld[u] = ((ri - R0 - hy) * RW + (ci - C0 - hx)) * CBF_PX_BYTES + (qa & 1) * 16 - zoff;
+      oidx[u] = ri * p + ci;
+      unsigned m = 0u;
+      if (pok[u]) {
+        for (int s = 0; s < S; ++s) {
+          const int tl = 2 * s + h1;
+          const int dy = tl / kw, dx = tl - dy * kw;
+          const int yy = ri + dy - hy, xx = ci + dx - hx;
+          if (tl < ntaps && yy >= 0 && yy < cycles && xx >= 0 && xx < p) m |= 1u << s;
+        }
+      }
+      vmask[u] = m;
+    }
+    __syncthreads();                                          // previous tile's readers are done
+    {                                                          // every slab of the branch's one output tile
+      const __bf16* __restrict__ src = a.W[br];
+      for (int f = wv; f < S * 3; f += 8)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(wl + (size_t)f * 1024), 16, 0, 0);
+    }
+    if (b_begin < b_end) dma_region(b_begin, 0);
+    int it = 0;
+    const f4 bv = *(const f4*)(a.bias + br * a.out_stride_br + 4 * qa);
+    const float inv = a.inv[br];
+    for (int b = b_begin; b < b_end; ++b) {
+      f4 acc[CBF_NU];
+#pragma unroll
+      for (int u = 0; u < CBF_NU; ++u) acc[u] = bv;
+      __syncthreads();                                        // region b and the weights have landed (vmcnt(0))
+      if (b + 1 < b_end) dma_region(b + 1, (it + 1) & 1);
+      const char* __restrict__ reg = rbuf0 + (size_t)(it & 1) * a.region_bytes;
+      ++it;
+      const char* __restrict__ wlane = wl + lane * 16;
+      if (kw == 7) conv_fast_row<NS, 7, 7>(acc, reg, wlane, ld, vmask, zoff, RW * CBF_PX_BYTES, h1 != 0);
+      else if (kw == 5) conv_fast_row<NS, 5, 5>(acc, reg, wlane, ld, vmask, zoff, RW * CBF_PX_BYTES, h1 != 0);
+      else conv_fast_row<NS, 3, 3>(acc, reg, wlane, ld, vmask, zoff, RW * CBF_PX_BYTES, h1 != 0);
+      const size_t nimg = (size_t)a.B * d->g_px_off[g] + (size_t)b * P;
+#pragma unroll
+      for (int u = 0; u < CBF_NU; ++u) {
+        if (u < nu && pok[u]) {
+          const int ch = br * a.out_stride_br;
+          const f4 v = NS == 2 ? acc[u] * inv : acc[u];
+          if (a.out_p3) store_px<NS == 2 ? 2 : 3>((__bf16*)a.out + ((nimg + oidx[u]) * (a.OUTC >> 4) + (ch >> 4)) * PXE, qa, v);
+          else *(f4*)((float*)a.out + (nimg + oidx[u]) * a.OUTC + ch + 4 * qa) = v;
+        }
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------- small elementwise stages
@@ -1902,14 +2123,16 @@ static int launch_conv(ConvArgs& ca, int B, int L, int grid_x, hipStream_t st) {
   return launch_conv_t<1>(ca, grid, lds, st);
 }
 
-struct ConvBfGeom { int NCO; size_t lds; int plane_bytes, region_bytes, wbytes, sgroup; };
+struct ConvBfGeom { int NCO; size_t lds; int plane_bytes, region_bytes, wbytes, sgroup; bool fast; };
 
 // LDS plan of the split conv engines for window length L (npieces = activation piece planes per region:
 // 3 bf16x3, 2 f16x2, 1 plain bf16); NCO = 0 when it does not fit.
 static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int cout, int npieces) {
-  ConvBfGeom gm = {0, 0, 0, 0, 0, 0};
+  ConvBfGeom gm = {0, 0, 0, 0, 0, 0, false};
   int region_px = 1, smax = 1;
+  bool sq357 = cout == 16;                                              // k_conv_bf_fast: mid <= 16, kernels 3x3 / 5x5 / 7x7
   for (int k = 0; k < nbr; ++k) {
+    if (!(kh[k] == kw[k] && (kh[k] == 3 || kh[k] == 5 || kh[k] == 7))) sq357 = false;
     if (kh[k] > 31 || kw[k] > 31) return gm;
     int v = conv_region_px(L, kh[k], kw[k]);
     if (v > region_px) region_px = v;
@@ -1919,6 +2142,13 @@ static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int
   gm.plane_bytes = ((region_px * CBF_PX_BYTES + 1023) & ~1023) + 64;     // whole DMA pieces + the zero pixel
   gm.region_bytes = npieces * gm.plane_bytes;
   const int nco_tot = cout / 16;
+  if (sq357 && region_px <= FTN_REGION_PX && !g_conv_generic) {
+    gm.fast = true; gm.NCO = 1; gm.sgroup = smax;
+    gm.plane_bytes = CBF_FAST_PLANE; gm.region_bytes = npieces * CBF_FAST_PLANE;
+    gm.wbytes = smax * 3 * 1024;
+    gm.lds = (size_t)gm.wbytes + 2 * (size_t)gm.region_bytes;
+    return gm;
+  }
   // Output tiles per workgroup: more tiles share every pixel fragment read.  When all slabs' weights do not fit
   // beside the two region buffers, they are staged in groups of `sgroup` slabs.
   for (int nco = nco_tot >= 4 ? 4 : (nco_tot >= 2 ? 2 : 1); nco >= 1; nco >>= 1) {
@@ -1971,6 +2201,18 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
     ca.order[jj + 1] = v;
   }
   dim3 grid(grid_x, ftn_cdiv(B, ca.bpw), ca.nbr * ca.nchunk);
+  if (gm.fast && ca.cin == 16 && ca.cout == 16) {
+    hipError_t e = hipSuccess;
+    if (nsplit == 3) e = hipFuncSetAttribute((const void*)k_conv_bf_fast<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
+    else if (nsplit == 2) e = hipFuncSetAttribute((const void*)k_conv_bf_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
+    else e = hipFuncSetAttribute((const void*)k_conv_bf_fast<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
+    if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_conv_bf_fast): %s", hipGetErrorString(e)); return (int)e; }
+    if (nsplit == 3) hipLaunchKernelGGL(k_conv_bf_fast<3>, grid, dim3(512), gm.lds, st, ca);
+    else if (nsplit == 2) hipLaunchKernelGGL(k_conv_bf_fast<2>, grid, dim3(512), gm.lds, st, ca);
+    else hipLaunchKernelGGL(k_conv_bf_fast<1>, grid, dim3(512), gm.lds, st, ca);
+    FTN_CHECK_LAUNCH();
+    return 0;
+  }
   if (nsplit == 3) return launch_conv_bf_n<3>(ca, gm, grid, st);
   if (nsplit == 2) return launch_conv_bf_n<2>(ca, gm, grid, st);
   return launch_conv_bf_n<1>(ca, gm, grid, st);
@@ -2146,6 +2388,11 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
         if (nsplit == 3) { if ((rc = launch_mlp_bf_c128<ACT, 3>(mb, xvec, Nmax, st))) return rc; }
         else if (nsplit == 2) { if ((rc = launch_mlp_bf_c128<ACT, 2>(mb, xvec, Nmax, st))) return rc; }
         else if ((rc = launch_mlp_bf_c128<ACT, 1>(mb, xvec, Nmax, st))) return rc;
+      } else if (g_mlp_u1 && mb.nsKM == 2 && mb.nsCP == 2 && mb.n_ot == 7) {
+        // one 16-pixel unit per wave, four waves per SIMD (see k_mlp_bf_u1)
+        if (nsplit == 3) { if ((rc = launch_mlp_bf_u1<ACT, 3, 2, 2, 7>(mb, xvec, Nmax, st))) return rc; }
+        else if (nsplit == 2) { if ((rc = launch_mlp_bf_u1<ACT, 2, 2, 2, 7>(mb, xvec, Nmax, st))) return rc; }
+        else if ((rc = launch_mlp_bf_u1<ACT, 1, 2, 2, 7>(mb, xvec, Nmax, st))) return rc;
       } else if (nsplit == 3) { if ((rc = launch_mlp_bf<ACT, 3>(mb, xvec, Nmax, st))) return rc; }
       else if (nsplit == 2) { if ((rc = launch_mlp_bf<ACT, 2>(mb, xvec, Nmax, st))) return rc; }
       else if ((rc = launch_mlp_bf<ACT, 1>(mb, xvec, Nmax, st))) return rc;

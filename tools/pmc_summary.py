@@ -32,7 +32,7 @@ fs = glob.glob(f"{d}/stats/*/*_kernel_stats.csv")
 if fs:
     for r in csv.DictReader(open(fs[0])):
         stats[short(r["Name"])] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, pct=float(r["Percentage"]))
-fetch, write, sq = counters("fetch"), counters("write"), counters("sq")
+fetch, write, sq, lds = counters("fetch"), counters("write"), counters("sq"), counters("lds")
 summary = {}
 for k, st in sorted(stats.items(), key=lambda kv: -kv[1]["pct"]):
     if k.startswith("__amd") or k.startswith("k_dft"):
@@ -49,6 +49,17 @@ for k, st in sorted(stats.items(), key=lambda kv: -kv[1]["pct"]):
     if mf and ga:
         e["mfma_util"] = mf / 1024.0 / (ga / 8.0)      # busy cycles per SIMD / kernel cycles per XCD
         e["clock_ghz_profiled"] = ga / 8.0 / (st["avg_us"] * 1e3)
+    for name in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVES"):
+        v = mean(sq[k].get(name, []))
+        if v is not None:
+            e[name] = v
+    for name in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY",
+                 "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS"):
+        v = mean(lds[k].get(name, []))
+        if v is not None:
+            e[name] = v
+    if e.get("SQ_LDS_IDX_ACTIVE"):
+        e["lds_conflict_frac"] = e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"]
     summary[k] = e
 json.dump(summary, open(f"{d}/summary.json", "w"), indent=1)
 print(f"{'kernel':44s} {'avg_us':>8s} {'pct':>6s} {'HBM MB':>8s} {'GB/s':>7s} {'mfma%':>6s}")

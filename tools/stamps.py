@@ -52,7 +52,7 @@ if which == "conv":
     edges = np.linspace(0, en.max(), 13)
     print("  active WGs at t:", [int(((st <= e) & (en > e)).sum()) for e in edges[:-1]])
 if which == "mlp" and (s[:, 7] > 0).all():
-    for name, a, b in (("chunk 1 work", 2, 7), ("wait vmcnt(0) (DMA)", 7, 5)):
+    for name, a, b in (("chunk 1 work", 2, 7), ("chunk 1 closing barrier", 7, 4), ("chunk 2 weight refill + barrier", 4, 6)):
         dt = (s[:, b] - s[:, a])
         print(f"{name:26s} mean {dt.mean():9.0f} cyc  p50 {np.median(dt):9.0f}  p90 {np.percentile(dt, 90):9.0f}")
 for name, a, b in (("stage", 0, 1), ("compute", 1, 2), ("store", 2, 3), ("total", 0, 3)):
