@@ -8,6 +8,7 @@
 //   k_finalize   S3-S5  mean, DC kill, log penalty, top-k (wave arg-max),
 //                       periods, grouping, tiling, softmax weights -> FtnDesc, amps, w
 #include <math.h>
+#include <stdlib.h>
 #include "ftn_common.h"
 
 // ---------------------------------------------------------------- twiddle table
@@ -103,6 +104,35 @@ __device__ __forceinline__ float wave_lower_median(const float* __restrict__ row
 // Four independent <= 64-element sorts interleaved in one instruction stream: the 21 dependent
 // compare-exchange steps of a single sort (each a cross-lane permute) leave the wave waiting on its own
 // latency chain, and every workgroup of the launch reaches this phase at the same time.
+// lane ^ J partner value without the LDS crossbar where DPP can do it: J = 1, 2 are quad permutes, J = 8 a
+// 16-lane row rotate, J = 4 two bank-masked row shifts (banks = groups of 4 lanes); J = 16, 32 go through
+// ds_bpermute.  18 of the 21 bitonic steps of a 64-element sort then cost VALU latency instead of LDS latency.
+template <int J>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int iv = __float_as_int(v);
+  if constexpr (J == 1) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false));       // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+  else if constexpr (J == 8) return __int_as_float(__builtin_amdgcn_update_dpp(iv, iv, 0x128, 0xF, 0xF, false)); // row_ror:8
+  else if constexpr (J == 4) {
+    int r = __builtin_amdgcn_update_dpp(iv, iv, 0x104, 0xF, 0x5, false);   // row_shl:4 -> lanes of banks 0, 2 read lane + 4
+    r = __builtin_amdgcn_update_dpp(r, iv, 0x114, 0xF, 0xA, false);         // row_shr:4 -> lanes of banks 1, 3 read lane - 4
+    return __int_as_float(r);
+  } else return __shfl_xor(v, J);
+}
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_step_x4(float (&v)[4], int lane) {
+  const bool up = (lane & K) == 0;                // K == 64: every lane index is below 64 -> ascending
+  const bool lower = (lane & J) == 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float other = lane_xor<J>(v[r]);
+    v[r] = (lower == up) ? fminf(v[r], other) : fmaxf(v[r], other);
+  }
+}
+
+// Four independent <= 64-element sorts interleaved in one instruction stream: the 21 dependent
+// compare-exchange steps of a single sort leave the wave waiting on its own latency chain.
 __device__ __forceinline__ void wave_lower_median_x4(const float* __restrict__ r0, const float* __restrict__ r1,
                                                      const float* __restrict__ r2, const float* __restrict__ r3,
                                                      int C, int lane, float (&m)[4]) {
@@ -111,86 +141,110 @@ __device__ __forceinline__ void wave_lower_median_x4(const float* __restrict__ r
   v[1] = lane < C ? r1[lane] : INFINITY;
   v[2] = lane < C ? r2[lane] : INFINITY;
   v[3] = lane < C ? r3[lane] : INFINITY;
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int jj = k >> 1; jj > 0; jj >>= 1) {
-      const bool up = (lane & k) == 0;            // k == 64: every lane index is below 64 -> ascending
-      const bool lower = (lane & jj) == 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float other = __shfl_xor(v[r], jj);
-        v[r] = (lower == up) ? fminf(v[r], other) : fmaxf(v[r], other);
-      }
-    }
-  }
+  bitonic_step_x4<2, 1>(v, lane);
+  bitonic_step_x4<4, 2>(v, lane); bitonic_step_x4<4, 1>(v, lane);
+  bitonic_step_x4<8, 4>(v, lane); bitonic_step_x4<8, 2>(v, lane); bitonic_step_x4<8, 1>(v, lane);
+  bitonic_step_x4<16, 8>(v, lane); bitonic_step_x4<16, 4>(v, lane); bitonic_step_x4<16, 2>(v, lane); bitonic_step_x4<16, 1>(v, lane);
+  bitonic_step_x4<32, 16>(v, lane); bitonic_step_x4<32, 8>(v, lane); bitonic_step_x4<32, 4>(v, lane);
+  bitonic_step_x4<32, 2>(v, lane); bitonic_step_x4<32, 1>(v, lane);
+  bitonic_step_x4<64, 32>(v, lane); bitonic_step_x4<64, 16>(v, lane); bitonic_step_x4<64, 8>(v, lane);
+  bitonic_step_x4<64, 4>(v, lane); bitonic_step_x4<64, 2>(v, lane); bitonic_step_x4<64, 1>(v, lane);
   const int t = (C - 1) >> 1;
 #pragma unroll
   for (int r = 0; r < 4; ++r) m[r] = __shfl(v[r], t);
 }
 
-__global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, int L, int C,
+__global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, int B, int L, int C,
                                                   const float* __restrict__ tab, int F, int FPAD,
-                                                  float* __restrict__ med) {
+                                                  float* __restrict__ med, int flat) {
   extern __shared__ __attribute__((aligned(16))) float amp[];  // [32][CS]
   const int CS = C + 1;
-  const int b = blockIdx.y, f0 = blockIdx.x * 32;
+  // Workgroup -> (batch row, 32-bin block).  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8),
+  // each with its own L2: all bin blocks of one batch row are given to the SAME XCD, back to back, so x[b] is
+  // fetched from HBM once and re-read from that L2 (a (bin block, b) grid spread a row's blocks over six
+  // XCDs and fetched it six times).  Speed only: any mapping is correct.
+  const int nfb = FPAD >> 5;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int b = flat ? (int)blockIdx.x / nfb : (slot / nfb) * 8 + xcd;
+  if (b >= B) return;
+  const int f0 = (flat ? (int)blockIdx.x % nfb : slot % nfb) * 32;
   const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 31, h = lane >> 5;
   const float* __restrict__ xb = x + (size_t)b * L * C;
   const float* __restrict__ ctab = tab + f0 + i;
   const float* __restrict__ stab = tab + (size_t)L * FPAD + f0 + i;
   const int nct = (C + 31) >> 5;
+  // Real input: X[f] = sum_t x[t] e^{-2 pi i f t / L} folds around t = L/2,
+  //   Re X[f] =  sum_{tau=0}^{L/2} ce[tau] cos(2 pi f tau / L),   ce[tau] = x[tau] + x[L - tau]
+  //   Im X[f] = -sum_{tau=1}^{(L-1)/2} co[tau] sin(2 pi f tau / L), co[tau] = x[tau] - x[L - tau]
+  // (tau = 0 and, for even L, tau = L/2 have no partner: ce = x[tau], co = 0), which halves the fp32 MFMA work
+  // of the DFT-as-GEMM - the pipe this kernel is bound by - for two extra VALU ops per sample.
+  const int KT = (L >> 1) + 1;                         // folded time steps tau = 0 .. L/2
   for (int ct = wave; ct < nct; ct += nw) {
     const int c = ct * 32 + i;
     const bool cok = c < C;
+    const int cc = cok ? c : 0;
     f16v re = {0}, im = {0};
-    // 8 k-steps (16 time samples) per iteration: 24 independent loads are in flight before
-    // the 16 MFMAs that consume them.  Addresses advance by constant strides (no per-load
-    // 64-bit multiply, no bounds test) in the main loop; the ragged tail is guarded.
-    const float* pc = ctab + (size_t)h * FPAD;
-    const float* ps = stab + (size_t)h * FPAD;
-    const float* px = xb + (size_t)h * C + (cok ? c : 0);
+    // 8 k-steps (16 folded samples) per iteration, two-deep software pipeline: the loads of block i+1 are issued
+    // before the MFMAs of block i (sched_barrier keeps hipcc from sinking them back next to their uses)
+    // one guarded k-step (tau = t + h): used for tau = 0, 1 and for the ragged end around L/2
+    auto step_guarded = [&](int t) {
+      const int tau = t + h;
+      const bool tok = tau < KT;
+      const int tt = tok ? tau : 0;
+      const bool pair = tok && tt > 0 && 2 * tt < L;          // has a distinct partner L - tau
+      const float xv = xb[(size_t)tt * C + cc];
+      const float xp = xb[(size_t)(pair ? L - tt : tt) * C + cc];
+      const float cv = tok ? ctab[(size_t)tt * FPAD] : 0.f;
+      const float sv = tok ? stab[(size_t)tt * FPAD] : 0.f;
+      const float e = (tok && cok) ? (pair ? xv + xp : xv) : 0.f;
+      const float o = (pair && cok) ? xv - xp : 0.f;
+      re = __builtin_amdgcn_mfma_f32_32x32x2f32(cv, e, re, 0, 0, 0);
+      im = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, o, im, 0, 0, 0);
+    };
+    step_guarded(0);
+    // interior: every tau in [2, tmid) has a distinct partner.  8 k-steps (16 folded samples) per iteration,
+    // two-deep software pipeline with constant-stride pointers (no bounds tests, no per-load multiplies):
+    // the loads of block i+1 are issued before the MFMAs of block i
+    const int nint = (L - 1) / 2 - 1 >= 2 ? (((L - 1) / 2 + 1 - 2) / 16) : 0;     // whole 16-sample blocks in [2, (L-1)/2]
     const int sT = 2 * FPAD, sX = 2 * C;
-    int t = 0;
-    // two-deep software pipeline: the loads of block i+1 are issued before the MFMAs of
-    // block i (sched_barrier keeps hipcc from sinking them back next to their uses)
-    float ac[8], as[8], bv[8];
-    if (L >= 16) {
+    const float* pc = ctab + (size_t)(2 + h) * FPAD;
+    const float* ps = stab + (size_t)(2 + h) * FPAD;
+    const float* px = xb + (size_t)(2 + h) * C + cc;
+    const float* pp = xb + (size_t)(L - 2 - h) * C + cc;
+    float ac[8], as[8], be[8], bo[8];
+    if (nint > 0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { ac[k] = pc[k * sT]; as[k] = ps[k * sT]; bv[k] = px[k * sX]; }
-      pc += 8 * sT; ps += 8 * sT; px += 8 * sX;
+      for (int k = 0; k < 8; ++k) {
+        const float xv = px[k * sX], xp = pp[-(k * sX)];
+        ac[k] = pc[k * sT]; as[k] = ps[k * sT]; be[k] = xv + xp; bo[k] = xv - xp;
+      }
+      pc += 8 * sT; ps += 8 * sT; px += 8 * sX; pp -= 8 * sX;
     }
-    for (; t + 16 <= L; t += 16) {
-      float an[8], sn[8], bn[8];
-      const bool more = t + 32 <= L;   // wave-uniform
+    for (int it = 0; it < nint; ++it) {
+      float an[8], sn[8], en[8], on[8];
+      const bool more = it + 1 < nint;   // wave-uniform
       if (more) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { an[k] = pc[k * sT]; sn[k] = ps[k * sT]; bn[k] = px[k * sX]; }
-        pc += 8 * sT; ps += 8 * sT; px += 8 * sX;
+        for (int k = 0; k < 8; ++k) {
+          const float xv = px[k * sX], xp = pp[-(k * sX)];
+          an[k] = pc[k * sT]; sn[k] = ps[k * sT]; en[k] = xv + xp; on[k] = xv - xp;
+        }
+        pc += 8 * sT; ps += 8 * sT; px += 8 * sX; pp -= 8 * sX;
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float xv = cok ? bv[k] : 0.f;
-        re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[k], xv, re, 0, 0, 0);
-        im = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k], xv, im, 0, 0, 0);
+        re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[k], cok ? be[k] : 0.f, re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k], cok ? bo[k] : 0.f, im, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (more) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { ac[k] = an[k]; as[k] = sn[k]; bv[k] = bn[k]; }
+        for (int k = 0; k < 8; ++k) { ac[k] = an[k]; as[k] = sn[k]; be[k] = en[k]; bo[k] = on[k]; }
       }
     }
-    for (; t < L; t += 2) {
-      const int tt = t + h;
-      const bool tok = tt < L;
-      const float ac = tok ? ctab[(size_t)tt * FPAD] : 0.f;
-      const float as = tok ? stab[(size_t)tt * FPAD] : 0.f;
-      const float bv = (tok && cok) ? xb[(size_t)tt * C + c] : 0.f;
-      re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bv, re, 0, 0, 0);
-      im = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bv, im, 0, 0, 0);
-    }
+    for (int t = 2 + 16 * nint; t < KT; t += 2) step_guarded(t);
     if (cok) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -238,22 +292,22 @@ __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, i
   }
 }
 
-// psum[f] = sum_b med[b][f] in fp64, fixed order: 8 row-strided partial sums per
-// column, combined in index order (bitwise reproducible; no atomics).
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ med, int B, int F,
-                                                double* __restrict__ psum) {
-  __shared__ double part[8][32];
+// psum[f] = sum_b med[b][f] in fp64, fixed order: 32 row-strided partial sums per column, combined in index
+// order (bitwise reproducible; no atomics).
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ med, int B, int F,
+                                                 double* __restrict__ psum) {
+  __shared__ double part[32][33];
   const int fl = threadIdx.x & 31, bl = threadIdx.x >> 5;
   const int f = blockIdx.x * 32 + fl;
   double s = 0.0;
   if (f < F)
-    for (int b = bl; b < B; b += 8) s += (double)med[(size_t)b * F + f];
+    for (int b = bl; b < B; b += 32) s += (double)med[(size_t)b * F + f];
   part[bl][fl] = s;
   __syncthreads();
   if (bl == 0 && f < F) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += part[k][fl];
+    for (int k = 0; k < 32; ++k) t += part[k][fl];
     psum[f] = t;
   }
 }
@@ -262,7 +316,7 @@ extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, cons
                                    float* med_dev, double* psum_dev, void* stream) {
   FTN_CHECK_ARG(x_dev && table_dev && med_dev && psum_dev, "ftn_period_spectrum: null pointer");
   FTN_CHECK_ARG(B >= 1 && L >= 2 && C >= 1, "ftn_period_spectrum: bad shape B=%d L=%d C=%d", B, L, C);
-  FTN_CHECK_ARG(B <= 65535, "ftn_period_spectrum: B=%d exceeds grid.y", B);
+  FTN_CHECK_ARG((long long)(B + 7) * (fpad_of(L) / 32) < 0x7fffffffLL, "ftn_period_spectrum: B=%d too large", B);
   const int F = L / 2 + 1, FPAD = fpad_of(L);
   const size_t lds = (size_t)32 * (C + 1) * sizeof(float);
   FTN_CHECK_ARG(lds <= 160 * 1024, "ftn_period_spectrum: C=%d too large for the LDS amplitude tile", C);
@@ -272,10 +326,11 @@ extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, cons
     hipError_t e = hipFuncSetAttribute((const void*)k_spectrum, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
-  hipLaunchKernelGGL(k_spectrum, dim3(FPAD / 32, B), dim3(64 * nw), lds, (hipStream_t)stream, x_dev, L, C,
-                     (const float*)table_dev, F, FPAD, med_dev);
+  const int nfb = FPAD / 32;
+  hipLaunchKernelGGL(k_spectrum, dim3((unsigned)(ftn_cdiv(B, 8) * 8 * nfb)), dim3(64 * nw), lds, (hipStream_t)stream, x_dev,
+                     B, L, C, (const float*)table_dev, F, FPAD, med_dev, getenv("FTN_SEL_FLAT") != nullptr ? 1 : 0);
   FTN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_colsum, dim3(ftn_cdiv(F, 32)), dim3(256), 0, (hipStream_t)stream, med_dev, B, F, psum_dev);
+  hipLaunchKernelGGL(k_colsum, dim3(ftn_cdiv(F, 32)), dim3(1024), 0, (hipStream_t)stream, med_dev, B, F, psum_dev);
   FTN_CHECK_LAUNCH();
   return 0;
 }
@@ -295,7 +350,6 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psu
                                                   int pmax, int min_thr, FtnDesc* __restrict__ desc,
                                                   float* __restrict__ amps, float* __restrict__ wts) {
   extern __shared__ __attribute__((aligned(16))) float score[];  // [F]
-  __shared__ ArgMax wbest[4];
   __shared__ int sel_idx[FTN_KMAX];
   __shared__ FtnDesc sd;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -312,52 +366,117 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psu
   int k = kcfg < F - 1 ? kcfg : F - 1;                            // :122-123
   if (k > FTN_KMAX) k = FTN_KMAX;
   if (k < 0) k = 0;
-  // top-k: k rounds of block arg-max; a taken bin is marked with NaN
-  for (int r = 0; r < k; ++r) {
-    ArgMax best = {0.f, -1};
-    for (int f = tid; f < F; f += 256) {
-      float v = score[f];
-      if (v == v) best = better(best, ArgMax{v, f});
+  // top-k by ONE wavefront, no barriers: every lane keeps the best of its strided share of the bins, a
+  // shuffle butterfly reduces the 64 candidates, the winner's bin is retired (NaN) and the lane that owned it
+  // rescans its share.  k <= 16 rounds of ~12 shuffles; ties resolve to the lowest bin index.
+  if (wave == 0) {
+    ArgMax mine = {0.f, -1};
+    for (int f = lane; f < F; f += 64) {
+      const float v = score[f];
+      if (v == v) mine = better(mine, ArgMax{v, f});
     }
-    for (int off = 32; off > 0; off >>= 1) {
-      ArgMax o;
-      o.v = __shfl_xor(best.v, off);
-      o.i = __shfl_xor(best.i, off);
-      best = better(best, o);
-    }
-    if (lane == 0) wbest[wave] = best;
-    __syncthreads();
-    if (tid == 0) {
-      ArgMax bb = wbest[0];
-      for (int w = 1; w < 4; ++w) bb = better(bb, wbest[w]);
-      sel_idx[r] = bb.i;
-      if (bb.i >= 0) score[bb.i] = __builtin_nanf("");
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    int periods[FTN_KMAX];
-    int nsel = 0;
-    const int hi = pmax < (L - 1 > 1 ? L - 1 : 1) ? pmax : (L - 1 > 1 ? L - 1 : 1);   // :138
-    const int lo = min_thr;                                                            // :139
-    for (int j = 0; j < FTN_KMAX; ++j) { sd.sel_freq[j] = 0; sd.sel_period[j] = 0; }
-    if (hi >= lo) {
-      for (int r = 0; r < k; ++r) {
-        int idx = sel_idx[r];
-        if (idx < 0) continue;
-        if (idx < 1) idx = 1;                                     // clamp_min(1) :132
-        int p = (L + idx - 1) / idx;                              // :144
-        p = p < lo ? lo : (p > hi ? hi : p);                      // :145
-        if ((L + p - 1) / p >= 2) {                               // :147-148
-          sd.sel_freq[nsel] = idx;
-          sd.sel_period[nsel] = p;
-          periods[nsel] = p;
-          ++nsel;
+    for (int r = 0; r < k; ++r) {
+      ArgMax best = mine;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        ArgMax o;
+        o.v = __shfl_xor(best.v, off);
+        o.i = __shfl_xor(best.i, off);
+        best = better(best, o);
+      }
+      if (lane == 0) sel_idx[r] = best.i;
+      if (best.i >= 0 && (best.i & 63) == lane) {          // owner: retire the bin, rescan its share
+        score[best.i] = __builtin_nanf("");
+        mine = ArgMax{0.f, -1};
+        for (int f = lane; f < F; f += 64) {
+          const float v = score[f];
+          if (v == v) mine = better(mine, ArgMax{v, f});
         }
       }
     }
-    sd.n_sel = nsel;
-    ftn_build_groups(periods, nsel, L, lo, pmax, &sd);            // grouper min/max = selector's (:972-973)
+  }
+  __syncthreads();
+  // periods, validity, grouping and tiling by the lanes of wave 0 in parallel - lane j owns candidate j, then
+  // group j (FTN_KMAX <= 64).  Integer division has no hardware instruction here (~40 VALU ops each), and the
+  // ~100 divisions of this section (period = ceil(L/idx), pad, cycles, the tile-geometry search) used to run one
+  // after another on a single lane: 13 us of a 24 us kernel.  Same results as ftn_build_groups (host).
+  if (wave == 0) {
+    const int hi = pmax < (L - 1 > 1 ? L - 1 : 1) ? pmax : (L - 1 > 1 ? L - 1 : 1);   // :138
+    const int lo = min_thr;                                                            // :139
+    // -- candidate j: period, kept by the selector? (:144-148)
+    int idx = (lane < k) ? sel_idx[lane] : -1;
+    bool kept = false;
+    int p = 0;
+    if (idx >= 0 && hi >= lo) {
+      if (idx < 1) idx = 1;                                       // clamp_min(1) :132
+      p = (L + idx - 1) / idx;                                    // :144
+      p = p < lo ? lo : (p > hi ? hi : p);                        // :145
+      kept = (L + p - 1) / p >= 2;                                // :147-148
+    }
+    const unsigned long long keptm = __ballot(kept);
+    const int nsel = __popcll(keptm);
+    const int slot = __popcll(keptm & ((1ull << lane) - 1ull));   // position among the kept candidates (score order)
+    if (lane < FTN_KMAX) { sd.sel_freq[lane] = 0; sd.sel_period[lane] = 0; sd.sel_group[lane] = -1; }
+    if (kept) { sd.sel_freq[slot] = idx; sd.sel_period[slot] = p; }
+    // -- grouping (PeriodGrouper.group, flags unset, :513-557): lane s < nsel now owns kept candidate s
+    // period of kept candidate `lane`: gather from its owner = the lane holding the (lane+1)-th set bit of keptm
+    int owner = 0;
+    {
+      unsigned long long m = keptm;
+      for (int t = 0; t < FTN_KMAX; ++t) {                        // t-th set bit -> lane t
+        const int bit = m ? __ffsll((unsigned long long)m) - 1 : 0;
+        if (t == lane) owner = bit;
+        m &= m - 1ull;
+      }
+    }
+    const int pc = __shfl(p, owner);                              // period of kept candidate `lane` (lane < nsel)
+    // grouper filter: p > 0, lo <= p <= pmax, cycles >= 2 (:517-543)
+    int pad = 0, cyc = 0;
+    bool valid = false;
+    if (lane < nsel && pc > 0 && pc >= lo && pc <= pmax) {
+      pad = (pc - (L % pc)) % pc;
+      cyc = (L + pad) / pc;
+      valid = cyc >= 2;
+    }
+    // distinct valid periods, ascending: first = no earlier candidate with the same period;
+    // rank = number of distinct valid periods below mine
+    bool first = valid;
+    int rank = 0;
+    for (int t = 0; t < FTN_KMAX; ++t) {
+      const int pt = __shfl(pc, t);
+      const bool vt = __shfl((int)valid, t) != 0;
+      if (vt && pt == pc && t < lane) first = false;
+    }
+    for (int t = 0; t < FTN_KMAX; ++t) {
+      const int pt = __shfl(pc, t);
+      const bool ft = __shfl((int)first, t) != 0;
+      if (ft && pt < pc) ++rank;
+    }
+    const int G = __popcll(__ballot(first));
+    if (valid) sd.sel_group[lane] = rank;
+    int tw = 0, th = 0, ntx = 0, nty = 0;
+    if (first) ftn_tile_geometry(cyc, pc, &tw, &th, &ntx, &nty);
+    if (lane < FTN_KMAX) {                                        // defaults for the unused group slots
+      sd.g_period[lane] = 0; sd.g_pad[lane] = 0; sd.g_cycles[lane] = 0;
+      sd.g_tw[lane] = 0; sd.g_th[lane] = 0; sd.g_ntx[lane] = 0; sd.g_nty[lane] = 0;
+    }
+    if (first) {
+      sd.g_period[rank] = pc; sd.g_pad[rank] = pad; sd.g_cycles[rank] = cyc;
+      sd.g_tw[rank] = tw; sd.g_th[rank] = th; sd.g_ntx[rank] = ntx; sd.g_nty[rank] = nty;
+    }
+    // prefix sums over the groups in ascending order: lane g re-reads group g (same wave: LDS ops are in order)
+    const int gpx = (lane < G) ? L + sd.g_pad[lane] : 0;
+    const int gtl = (lane < G) ? sd.g_ntx[lane] * sd.g_nty[lane] : 0;
+    int opx = 0, otl = 0;                                         // exclusive prefix of lanes < lane
+    for (int t = 0; t < FTN_KMAX; ++t) {
+      const int a_ = __shfl(gpx, t), b_ = __shfl(gtl, t);
+      if (t < lane) { opx += a_; otl += b_; }
+    }
+    if (lane <= FTN_KMAX) { sd.g_px_off[lane] = opx; sd.g_tile_off[lane] = otl; }   // lanes >= G hold the totals
+    if (lane == 0) {
+      sd.n_sel = nsel; sd.n_groups = G;
+    }
+    if (lane == FTN_KMAX) { sd.total_px = opx; sd.tiles_per_row = otl; }
   }
   __syncthreads();
   // write the descriptor (whole struct, cooperatively)

@@ -68,6 +68,15 @@ def test_selector_matches_reference(name, manifest, golden, ftn, dev):
     assert sel.last_frequency_indices.tolist() == g["freq_idx"].tolist()
     np.testing.assert_allclose(amps.cpu().numpy(), g["amps"], rtol=RTOL, atol=1e-4 * float(np.abs(g["median"]).max()))
     med, psum = ftn.runtime.spectrum(x.contiguous())
+    # the device-built descriptor (wave-parallel grouping in k_finalize) == the host's ftn_desc_from_periods
+    dd = sel._pending.host() if sel._pending is not None else None
+    if dd is not None:
+        n = int(dd.n_sel)
+        hd = ftn.lib.desc_from_periods(list(dd.sel_period[:n]), case["L"], sel.min_period_threshold, sel.pmax)
+        for fld in ("g_period", "g_pad", "g_cycles", "g_px_off", "g_tw", "g_th", "g_ntx", "g_nty", "g_tile_off",
+                    "sel_group"):
+            assert list(getattr(dd, fld)) == list(getattr(hd, fld)), fld
+        assert (dd.n_groups, dd.total_px, dd.tiles_per_row) == (hd.n_groups, hd.total_px, hd.tiles_per_row)
     scale = float(np.abs(g["median"]).max())
     np.testing.assert_allclose(med.cpu().numpy(), g["median"], rtol=RTOL, atol=2e-6 * scale)
     np.testing.assert_allclose(psum.cpu().numpy() / case["B"], g["amp_mean"], rtol=RTOL, atol=2e-6 * scale)
