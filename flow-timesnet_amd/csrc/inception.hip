@@ -101,24 +101,29 @@ __device__ __forceinline__ f4 load_x4(const float* __restrict__ xrow, int c, int
   return v;
 }
 
-// ---------------------------------------------------------------- stages A / E
-// out = W.in + b              (EPI 0)
-// R   = act(W.in + b) + R     (EPI 1, in place)
-template <int ACT, bool XIN, bool XVEC, int EPI>
+// ---------------------------------------------------------------- stage A and the generic pointwise layers
+// out[n][:] = epilogue( W in[n][:] + b )  on exact fp32 MFMA, any number of output tiles and any K.
+//   XIN 0: in = buffer [N][KIN] per grid pixel      XIN 1: in = x by window row (stage A, see below)
+//   XIN 2: in = x by grid pixel (zero rows for the live pad pixels t >= L)
+//   EPI 0: store fp32      EPI 2 / 3: store three bf16 / two fp16 pieces (input of the split conv engines)
+//   EPI 4: store v - x[n]  (r = res2(g) - x)      EPI 5: store act(v)      EPI 6: out = act(v + out)  (in place)
+// Stage A always runs here; EPI 4-6 with XIN 0 / 2 form the generic stage C for widths beyond the fused
+// kernels' limits (more than 16 output tiles, or a hidden chunk's fragments not fitting LDS twice).
+template <int ACT, int XIN, bool XVEC, int EPI>
 __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
-  // XIN (stage A): a = W_in1 x + b depends on (b, t) only, not on the period group, so it is computed once per
+  // XIN 1 (stage A): a = W_in1 x + b depends on (b, t) only, not on the period group, so it is computed once per
   // window position - rows n = b*L + t of `out` - plus ONE pad row n = B*L for the live zero pixels t >= L of
   // every grid (x = 0 there, :1017, so a = bias).  The conv stage folds these rows into its period grids while
   // staging (ConvArgs.bt_L), which is the reference's reshape (:1041-1046) done by index arithmetic.
   const FtnDesc* __restrict__ d = a.desc;
-  const int N = XIN ? a.B * a.L + 1 : a.B * d->total_px;
+  const int N = XIN == 1 ? a.B * a.L + 1 : a.B * d->total_px;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int n0 = (blockIdx.x * 4 + wave) * (16 * NPXU);
   if (n0 >= N) return;
   Px px[NPXU];
 #pragma unroll
   for (int u = 0; u < NPXU; ++u) {
-    if (XIN) {
+    if (XIN == 1) {
       const int n = n0 + 16 * u + j;
       px[u].ok = n < N;
       px[u].n = px[u].ok ? n : N - 1;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
       f4 bf[NPXU];
 #pragma unroll
       for (int u = 0; u < NPXU; ++u) {
-        if (XIN) bf[u] = load_x4<XVEC>(px[u].xrow, s + 4 * q, a.C);
+        if (XIN != 0) bf[u] = load_x4<XVEC>(px[u].xrow, s + 4 * q, a.C);
         else bf[u] = *(const f4*)(a.in + (size_t)px[u].n * KIN + s + 4 * q);
       }
 #pragma unroll
@@ -162,19 +167,40 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
         for (int u = 0; u < NPXU; ++u) {
           if (!px[u].ok) continue;
           const int ch = 16 * (og + o) + 4 * q;
+          float* op = a.out + (size_t)px[u].n * a.OUTC + ch;
           if (EPI == 0) {
-            *(f4*)(a.out + (size_t)px[u].n * a.OUTC + ch) = acc[o][u];
+            *(f4*)op = acc[o][u];
           } else if (EPI == 2 || EPI == 3) {   // bf16x3 (P3) / f16x2 (H2) pieces: input of the split conv engines
             constexpr int NSP = EPI == 3 ? 2 : 3;
             store_px<NSP>((__bf16*)a.out + ((size_t)px[u].n * (a.OUTC >> 4) + (og + o)) * PxFmt<NSP>::ELEMS, q, acc[o][u]);
+          } else if (EPI == 4) {
+            *(f4*)op = acc[o][u] - load_x4<XVEC>(px[u].xrow, ch, a.C);
+          } else if (EPI == 5) {
+            *(f4*)op = act4<ACT>(acc[o][u]);
           } else {
-            float* rp = a.R + (size_t)px[u].n * a.RC + ch;
-            const f4 r = *(const f4*)rp;
-            *(f4*)rp = act4<ACT>(acc[o][u]) + r;
+            *(f4*)op = act4<ACT>(acc[o][u] + *(const f4*)op);
           }
         }
       }
     }
+  }
+}
+
+// Elementwise pieces of the generic stage C when a res_proj is the identity (d_ff == d_model):
+//   mode 0: g = act(g + x)      mode 1: r = g - x      (rows = grid pixels, CH = FP = CP channels)
+template <int ACT, bool XVEC>
+__global__ void k_ew_ident(const float* __restrict__ x, float* __restrict__ g, float* __restrict__ r,
+                           const FtnDesc* __restrict__ d, int B, int L, int C, int CH, int mode) {
+  const int N = B * d->total_px;
+  const int cq = CH >> 2;
+  const long long total = (long long)N * cq;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(e / cq), c = (int)(e - (long long)n * cq) * 4;
+    const Px px = decode_px(d, x, B, L, C, n, N);
+    const f4 xv = load_x4<XVEC>(px.xrow, c, C);
+    f4* gp = (f4*)(g + (size_t)n * CH + c);
+    if (mode == 0) *gp = act4<ACT>(*gp + xv);
+    else *(f4*)(r + (size_t)n * CH + c) = *gp - xv;
   }
 }
 
@@ -2039,6 +2065,15 @@ static int conv_region_px(int L, int kh, int kw) {
   return worst;
 }
 
+// Stage C runs as separate generic pointwise launches (k_pw) when the fused kernels cannot take the shape: more
+// than 16 output tiles (nbr*mid/16 + d_model/16), or a hidden chunk's weight fragments not fitting LDS twice.
+static bool stagec_generic(const FtnPlan* pl) {
+  if (pl->mode != 0) return false;
+  const int CA = pl->nbr * pl->MP;
+  const int n_ot = CA / 16 + (pl->res2 ? pl->CP / 16 : 0);
+  return n_ot > 16 || pl->cfrag_per_chunk <= 0 || (size_t)pl->cfrag_per_chunk * 1024 * 2 > 160 * 1024;
+}
+
 struct WsLayout {
   size_t offA, off0, off1, off2, off3, total;
   int c0, c1;  // channel counts of buf0 / buf1
@@ -2060,7 +2095,7 @@ static WsLayout ws_layout(const FtnPlan* pl, int B, int L, int max_groups, int p
   w.off1 = al(w.off0 + N * w.c0 * bpv);
   w.off2 = al(w.off1 + N * w.c1 * bpv);               // R [N][CP]
   w.off3 = al(w.off2 + N * pl->CP * 4);               // G [N][FP] (mode 1)
-  w.total = pl->mode == 0 ? w.off3 : al(w.off3 + N * pl->FP * 4);
+  w.total = (pl->mode == 0 && !stagec_generic(pl)) ? w.off3 : al(w.off3 + N * pl->FP * 4);
   return w;
 }
 
@@ -2218,7 +2253,7 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
   return launch_conv_bf_n<1>(ca, gm, grid, st);
 }
 
-template <int ACT, bool XIN, int EPI>
+template <int ACT, int XIN, int EPI>
 static int launch_pw(const PwArgs& pa, bool xvec, int nblk, hipStream_t st) {
   if (xvec) hipLaunchKernelGGL((k_pw<ACT, XIN, true, EPI>), dim3(nblk), dim3(256), 0, st, pa);
   else hipLaunchKernelGGL((k_pw<ACT, XIN, false, EPI>), dim3(nblk), dim3(256), 0, st, pa);
@@ -2330,9 +2365,9 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     PwArgs pa = {};
     pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = bufA; pa.desc = desc;
     pa.B = B; pa.L = L; pa.C = C; pa.KIN = CP; pa.n_ot = CA / 16; pa.OUTC = CA;
-    if (use_bf && h2) { if ((rc = launch_pw<ACT, true, 3>(pa, xvec, nblk_pw, st))) return rc; }
-    else if (use_bf) { if ((rc = launch_pw<ACT, true, 2>(pa, xvec, nblk_pw, st))) return rc; }
-    else if ((rc = launch_pw<ACT, true, 0>(pa, xvec, nblk_pw, st))) return rc;
+    if (use_bf && h2) { if ((rc = launch_pw<ACT, 1, 3>(pa, xvec, nblk_pw, st))) return rc; }
+    else if (use_bf) { if ((rc = launch_pw<ACT, 1, 2>(pa, xvec, nblk_pw, st))) return rc; }
+    else if ((rc = launch_pw<ACT, 1, 0>(pa, xvec, nblk_pw, st))) return rc;
     prof_mark(1, st);
     ConvBfArgs cb = {};
     // stage C on the bf16 pipe too when the plan carries its fragments and the shapes fit
@@ -2370,8 +2405,37 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ma.n_hchunks = pl->n_hchunks; ma.cfrag_per_chunk = pl->cfrag_per_chunk;
     ma.n_oa = CA / 16; ma.res2_ident = pl->res2 ? 0 : 1; ma.n_ot = ma.n_oa + (pl->res2 ? CP / 16 : 0);
     ma.outA_p3 = use_bf ? (h2 ? 2 : 1) : 0;
-    if (ma.n_ot > 16) { ftn_set_error("stage C needs %d output tiles (>16): d_model/mid too large for v1", ma.n_ot); return -1; }
-    if (ma.cfrag_per_chunk != MLP_HT * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
+    const bool generic_c = !(mlp_bf || mlp_bf128) && stagec_generic(pl);
+    if (!generic_c && !(mlp_bf || mlp_bf128) && ma.cfrag_per_chunk != MLP_HT * (ma.nKM + ma.nCP + ma.n_ot)) { ftn_set_error("plan/cfrag layout mismatch"); return -1; }
+    if (generic_c) {
+      // wide blocks: the chain as pointwise launches with the hidden tensor g in the workspace
+      //   g1 = act(W_out1 m + b);  g = act(g1 + res1(x));  a' = W_in2 g + b;  r = res2(g) - x
+      const int nblk_px = (int)((Nmax + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));
+      PwArgs pg = {};
+      pg.x = x; pg.desc = desc; pg.B = B; pg.L = L; pg.C = C;
+      pg.in = buf1; pg.W = wb + pl->w_out1; pg.bias = wb + pl->b_out1; pg.out = bufG; pg.KIN = CA; pg.n_ot = FP / 16; pg.OUTC = FP;
+      if ((rc = launch_pw<ACT, 0, 5>(pg, xvec, nblk_px, st))) return rc;
+      if (pl->res1) {
+        pg.in = nullptr; pg.W = wb + pl->w_res1; pg.bias = wb + pl->b_res1; pg.KIN = CP;
+        if ((rc = launch_pw<ACT, 2, 6>(pg, xvec, nblk_px, st))) return rc;
+      } else {
+        if (xvec) hipLaunchKernelGGL((k_ew_ident<ACT, true>), dim3(nblk_ew), dim3(256), 0, st, x, bufG, bufR, desc, B, L, C, FP, 0);
+        else hipLaunchKernelGGL((k_ew_ident<ACT, false>), dim3(nblk_ew), dim3(256), 0, st, x, bufG, bufR, desc, B, L, C, FP, 0);
+        FTN_CHECK_LAUNCH();
+      }
+      pg.in = bufG; pg.W = wb + pl->w_in2; pg.bias = wb + pl->b_in2; pg.out = buf0; pg.KIN = FP; pg.n_ot = CA / 16; pg.OUTC = CA;
+      if (use_bf && h2) { if ((rc = launch_pw<ACT, 0, 3>(pg, xvec, nblk_px, st))) return rc; }
+      else if (use_bf) { if ((rc = launch_pw<ACT, 0, 2>(pg, xvec, nblk_px, st))) return rc; }
+      else if ((rc = launch_pw<ACT, 0, 0>(pg, xvec, nblk_px, st))) return rc;
+      if (pl->res2) {
+        pg.W = wb + pl->w_res2; pg.bias = wb + pl->b_res2; pg.out = bufR; pg.n_ot = CP / 16; pg.OUTC = CP;
+        if ((rc = launch_pw<ACT, 0, 4>(pg, xvec, nblk_px, st))) return rc;
+      } else {
+        if (xvec) hipLaunchKernelGGL((k_ew_ident<ACT, true>), dim3(nblk_ew), dim3(256), 0, st, x, bufG, bufR, desc, B, L, C, FP, 1);
+        else hipLaunchKernelGGL((k_ew_ident<ACT, false>), dim3(nblk_ew), dim3(256), 0, st, x, bufG, bufR, desc, B, L, C, FP, 1);
+        FTN_CHECK_LAUNCH();
+      }
+    } else
     if (mlp_bf || mlp_bf128) {
       MlpBfArgs mb = {};
       mb.x = x; mb.m = (const __bf16*)buf1; mb.cfrag = (const __bf16*)(wb + pl->w_cfragbf);

@@ -388,9 +388,16 @@ def pack_inception(
         if plan.res1:
             Wr1 = np.zeros((FP, CP)); Wr1[:F, :C] = sd["0.res_proj.weight"][:, :, 0, 0]
         nKM, nCP, n_ot = CA // 16, (CP // 16 if plan.res1 else 0), Wc.shape[0] // 16
-        cf = _pack_cfrag(W_out1, Wr1, Wc, FP, nKM, nCP, n_ot)
-        plan.w_cfrag = blob.add(cf)
-        plan.cfrag_per_chunk, plan.n_hchunks = CHUNK_TILES * (nKM + nCP + n_ot), cf.shape[0]
+        per = CHUNK_TILES * (nKM + nCP + n_ot)
+        plan.n_hchunks = (FP + 16 * CHUNK_TILES - 1) // (16 * CHUNK_TILES)
+        if n_ot > 16 or per * 1024 * 2 > 160 * 1024:
+            # beyond the fused stage-C kernels (csrc/inception.hip stagec_generic): the chain runs as generic
+            # pointwise launches on the row-major matrices, no fragments needed
+            plan.w_cfrag, plan.cfrag_per_chunk = 0, 0
+        else:
+            cf = _pack_cfrag(W_out1, Wr1, Wc, FP, nKM, nCP, n_ot)
+            plan.w_cfrag = blob.add(cf)
+            plan.cfrag_per_chunk = per
         for j in range(nk):
             plan.w_convbf1[j] = blob.add(convs_bf[j])
             plan.w_convbf2[j] = blob.add(convs_bf[nk + j])
@@ -404,7 +411,8 @@ def pack_inception(
             for j in range(nk):
                 plan.sc_conv1[j], plan.sc_conv2[j] = conv_sc[j], conv_sc[nk + j]
             plan.b_conv1s, plan.b_conv2s = blob.add(b_conv1 * s1), blob.add(b_conv2 * s2)
-        if plan.res1 and plan.res2:
+        tuned = (32 < CA <= 64 and 32 < CP <= 64 and n_ot <= 8) or (CA == 96 and CP == 128 and n_ot == 14)
+        if plan.res1 and plan.res2 and tuned:         # shapes the split-engine stage-C kernels exist for
             nsKM, nsCP = (CA + 31) // 32, (CP + 31) // 32
             if h2:
                 plan.sc_out1, plan.sc_res1 = pow2_scale(W_out1), pow2_scale(Wr1)

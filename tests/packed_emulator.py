@@ -149,12 +149,14 @@ def emulate_h2(x, blob, plan, group_periods, weights):
     """The f16x2 engine's arithmetic (bottleneck mode with both res_proj convs): fp32 stage A and E as in
     ``emulate``; conv and stage-C GEMMs from the packed fp16 pieces, prescaled biases and scales of the plan."""
     assert plan.mode == 0 and plan.engine == 3 and plan.res1 and plan.res2
+    split_c = plan.cfragbf_per_chunk > 0      # stage C on the fp16 pipe only for the tuned shapes; fp32 MFMA otherwise
     B, L, C = x.shape
     CP, FP, act, MP = plan.CP, plan.FP, plan.act, plan.MP
     CA = plan.nbr * MP
     xp = np.zeros((B, L, CP)); xp[:, :, :C] = x
     y = x.astype(np.float64).copy()
-    Wo, Wr, Wc = _unpack_cfrag_h2(blob, plan, CA, CP, FP)
+    if split_c:
+        Wo, Wr, Wc = _unpack_cfrag_h2(blob, plan, CA, CP, FP)
     for g, p in enumerate(group_periods):
         pad = (-L) % p
         P = L + pad
@@ -177,12 +179,19 @@ def emulate_h2(x, blob, plan, group_periods, weights):
 
         a = u @ _mat(blob, plan.w_in1, CA, CP).T + _vec(blob, plan.b_in1, CA)               # A (fp32 MFMA)
         m = gconv(a, plan.w_convbf1, plan.b_conv1s, plan.sc_conv1)                           # B
-        z = (_h2_matmul(m, Wo) + _vec(blob, plan.b_out1s, FP)) / plan.sc_out1               # C layer 1
-        hacc = _act(z, act) * plan.sc_res1 + _vec(blob, plan.b_res1s, FP) + _h2_matmul(u[:, :, :CP], Wr)
-        gh = _act(hacc / plan.sc_res1, act)
-        oc = _h2_matmul(gh, Wc) + _vec(blob, plan.b_c2s, CA + CP)
-        a2 = oc[:, :, :CA] / plan.sc_a2
-        r = oc[:, :, CA:] / plan.sc_r2 - u
+        if split_c:
+            z = (_h2_matmul(m, Wo) + _vec(blob, plan.b_out1s, FP)) / plan.sc_out1           # C layer 1
+            hacc = _act(z, act) * plan.sc_res1 + _vec(blob, plan.b_res1s, FP) + _h2_matmul(u[:, :, :CP], Wr)
+            gh = _act(hacc / plan.sc_res1, act)
+            oc = _h2_matmul(gh, Wc) + _vec(blob, plan.b_c2s, CA + CP)
+            a2 = oc[:, :, :CA] / plan.sc_a2
+            r = oc[:, :, CA:] / plan.sc_r2 - u
+        else:
+            z = m @ _mat(blob, plan.w_out1, FP, CA).T + _vec(blob, plan.b_out1, FP)
+            gh = _act(_act(z, act) + u @ _mat(blob, plan.w_res1, FP, CP).T + _vec(blob, plan.b_res1, FP), act)
+            oc = gh @ _mat(blob, plan.w_c2, CA + CP, FP).T + _vec(blob, plan.b_c2, CA + CP)
+            a2 = oc[:, :, :CA]
+            r = oc[:, :, CA:] - u
         m2 = gconv(a2, plan.w_convbf2, plan.b_conv2s, plan.sc_conv2)                         # D
         z2 = m2 @ _mat(blob, plan.w_out2, CP, CA).T + _vec(blob, plan.b_out2, CP)           # E (fp32 MFMA)
         delta = _act(z2, act) + r

@@ -578,3 +578,36 @@ def test_many_periods(K, L, C, hyper, ftn, dev):
     assert blk.period_selector.last_selected_periods.tolist() == aux.sel.periods
     assert blk._last_group_count == len(aux.groups.periods) and blk._last_raw_period_count == len(aux.sel.periods)
     np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
+# ---- wide blocks: more than 16 stage-C output tiles, or a hidden chunk beyond the LDS budget, run
+#      the chain as generic pointwise launches; the reference's search space tunes d_model up to 512
+@pytest.mark.parametrize("engine", ["f16x2", "f32"])
+@pytest.mark.parametrize("C,d_ff,ratio,ks,L,B", [
+    (192, 768, 4.0, [(3, 3), (5, 5), (7, 7)], 96, 2),      # 9 + 12 = 21 output tiles
+    (256, 1024, 4.0, [(3, 3), (5, 5), (7, 7)], 96, 2),     # 12 + 16 = 28
+    (512, 2048, 4.0, [(3, 3), (5, 5)], 48, 2),             # mid 128: 16 + 32 = 48, hidden chunks of 2 x 64 fragments
+    (128, 512, 2.0, [(3, 3), (5, 5), (7, 7)], 96, 3),      # ratio 2: mid 64 -> 12 + 8 = 20
+    (384, None, 4.0, [(3, 3), (5, 5), (7, 7)], 60, 2),     # d_ff == d_model: identity res_proj twice, 18 tiles
+    (72, 288, 1.5, [(3, 3), (5, 5)], 80, 3),               # odd ratio: mid 48, d_model not a multiple of 16
+])
+def test_wide_blocks_match_oracle(C, d_ff, ratio, ks, L, B, engine, ftn, dev):
+    T = ftn.models.timesnet
+    blk = T.TimesBlock(C, ks, 0.0, "gelu", d_ff=d_ff, bottleneck_ratio=ratio)
+    blk.engine = engine
+    sd = ftn.synth.make_inception_params(C, d_ff if d_ff is not None else C, ks, ratio, 41)
+    blk.inception.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    blk = blk.eval().to(dev)
+    blk.period_selector = T.FFTPeriodSelector(3, L)
+    x = torch.from_numpy(ftn.synth.make_input(B, L, C, seed=8, planted=(24, 12, 8)))
+    P = {k: torch.from_numpy(v) for k, v in sd.items()}
+    y_ref, aux = orc.timesblock_forward(x, P, ks, "gelu", 3, L)
+    ln = torch.nn.LayerNorm(C).to(dev)
+    with torch.inference_mode():
+        y = blk(x.to(dev))
+        z = blk(x.to(dev), post_norm=ln)
+    assert blk._last_backend == "hip"
+    assert blk.period_selector.last_selected_periods.tolist() == aux.sel.periods
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL)
+    want = torch.nn.functional.layer_norm(y, (C,), ln.weight, ln.bias, ln.eps)
+    np.testing.assert_allclose(z.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=3e-6)

@@ -80,7 +80,8 @@ def test_packed_weights_reproduce_reference(name, manifest, golden, ftn):
     np.testing.assert_allclose(y, g["y"], rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["b_tiny_pipe", "b_c0_pipe", "b_c0_rect", "b_odd_pipe", "s_wide_rows", "s_448", "b_noise_pipe"])
+@pytest.mark.parametrize("name", ["b_tiny_pipe", "b_c0_pipe", "b_c0_rect", "b_odd_pipe", "s_wide_rows", "s_448", "b_noise_pipe",
+                                  "b_c1_pipe"])
 def test_f16x2_packed_pieces_reproduce_reference(name, manifest, golden, ftn):
     """The f16x2 engine on the CPU: the packed fp16 weight pieces (three per prescaled fragment), two-piece
     activations, prescaled biases and scales replayed in numpy must give the reference's outputs - this pins
@@ -90,6 +91,7 @@ def test_f16x2_packed_pieces_reproduce_reference(name, manifest, golden, ftn):
     sd = ftn.synth.make_inception_params(C, d_ff, ks, ratio, case["seed"])
     blob, plan = ftn.pack.pack_inception(sd, C, d_ff, ks, ratio, act, "f16x2")
     assert plan.engine == 3 and blob.size == plan.total_floats
+    assert (plan.cfragbf_per_chunk > 0) == (name == "b_c1_pipe")          # only d_model 64 / 128 pipeline shapes are tuned
     for sc in list(plan.sc_conv1)[:plan.nbr] + [plan.sc_out1, plan.sc_res1, plan.sc_a2, plan.sc_r2]:
         assert sc > 0 and float(np.log2(sc)).is_integer()                 # powers of two: prescaling is exact
     periods, amps = g["periods"].tolist(), torch.from_numpy(g["amps"])
