@@ -37,7 +37,7 @@ static unsigned long long* g_stamp_buf = nullptr;
 static size_t g_stamp_cap = 0;
 static int g_stamp_which = 0;  // 1: k_conv, 2: k_mlp
 static const bool g_conv_generic = [] { const char* e = getenv("FTN_CONV_GENERIC"); return e != nullptr && e[0] == '1'; }();  // experiment switch
-static const bool g_mlp_u1 = [] { const char* e = getenv("FTN_MLP_U1"); return e != nullptr && e[0] == '1'; }();   // experiment switch
+static const bool g_mlp_u1 = [] { const char* e = getenv("FTN_MLP_U1"); return e == nullptr || e[0] != '0'; }();    // 0: the two-unit k_mlp_bf
 __device__ __forceinline__ void stamp(unsigned long long* buf, size_t cap, size_t wg, int slot) {
   if (buf != nullptr && threadIdx.x == 0 && (wg * 8 + slot) < cap) buf[wg * 8 + slot] = __builtin_amdgcn_s_memtime();
 }
