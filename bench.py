@@ -302,6 +302,8 @@ def run_rank(args) -> None:
         nominal = 2.0 * pkg.pack.macs_per_pixel(C, F, ks, ratio) * px
         executed = 2.0 * pkg.pack.macs_per_pixel(C, F, ks, ratio, folded=True) * px
         conv_ms = sum(stage_ms)
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this same command (tools/profile2.sh:
+        # FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs); keys are kernel names, matched by prefix
         pmc_k = {}
         pmc = ROOT / "profiles" / "pmc_latest.json"
         if pmc.exists():
@@ -309,11 +311,18 @@ def run_rank(args) -> None:
                 pmc_k = json.loads(pmc.read_text())["kernels"]
             except Exception:
                 pmc_k = {}
+
+        def pmc_bytes(prefixes):
+            tot = 0.0
+            for k, v in pmc_k.items():
+                if any(k.startswith(pf) for pf in prefixes) and v.get("hbm_bytes") is not None:
+                    tot += float(v["hbm_bytes"])
+            return tot or None
+
         kname = STAGES[dom].split("(")[-1].rstrip(")")
-        traffic = pmc_k.get(kname, {}).get("hbm_bytes_per_launch")
+        traffic = pmc_bytes([kname])
         sel_bytes = 4.0 * B * L * C
-        sel_counter = sum(v.get("hbm_bytes_per_launch", 0.0) for k, v in pmc_k.items()
-                          if k in ("k_spectrum", "k_colsum", "k_finalize", "k_select")) or None
+        sel_counter = pmc_bytes(["k_spectrum", "k_colsum", "k_finalize"])
         out = {
             "metric": "TimesBlock-forward series/sec (B=256 L=336 N=512)",
             "value": value, "unit": "series/s", "n_gpus": dist_world if use_dist else 1, "steps": args.steps,
