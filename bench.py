@@ -256,6 +256,23 @@ def run_rank(args) -> None:
         torch.cuda.synchronize()
         sel_us = e0.elapsed_time(e1) / 20 * 1e3
         step()                                       # leave the block's lazy counters on a full forward
+    ms_graph = None
+    if world == 1 and not args.no_extras:
+        # the same step captured once and replayed as ONE hipGraphLaunch: what remains of the eager step's
+        # inter-kernel launch gaps (extra; `value` is the eager number)
+        gf = pkg.graph.GraphedForward(blk, x)
+        for _ in range(3):
+            gf.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            gf.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_graph = e0.elapsed_time(e1) / args.steps
+        del gf
+        with torch.inference_mode():
+            step()
     assert blk._last_backend == "hip"
     elapsed = t1 - t0
     if use_dist:
@@ -362,6 +379,8 @@ def run_rank(args) -> None:
         }
         if ms_gather is not None:
             out["ms_per_step_with_output_allgather"] = ms_gather
+        if ms_graph is not None:
+            out["ms_per_step_hip_graph"] = ms_graph
         if world == 1 and not args.no_extras:
             out["lrtc"] = lrtc_bench(pkg, dev, B, L, NS)
             out["model_forward"] = model_bench(pkg, dev, B, L, NS, C, ks, ratio, K)

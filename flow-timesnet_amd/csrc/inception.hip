@@ -51,7 +51,22 @@ struct PwArgs {
   float* R;              // [N][RC] (EPI 1: read, add, store back)
   const FtnDesc* desc;
   int B, L, C, KIN, n_ot, OUTC, RC;
+  // stage A also publishes the sanitised descriptor copy every later launch reads (guard_desc below); it does
+  // not need the descriptor itself, so this costs no extra launch
+  const FtnDesc* guard_src; FtnDesc* guard_dst; int guard_groups, guard_px;
 };
+
+// Copies the caller's descriptor to the head of the workspace; a descriptor that exceeds the bounds the
+// workspace and the grids were sized for (more groups than max_groups, more pixels than px_bound) is
+// replaced by an empty one, which makes the call the identity y = x instead of a write past a buffer.
+__device__ __forceinline__ void guard_desc(const FtnDesc* __restrict__ src, FtnDesc* __restrict__ dst, int max_groups,
+                                           int px_bound) {
+  const int* s = (const int*)src;
+  int* d = (int*)dst;
+  const bool bad = src->n_groups < 0 || src->n_groups > max_groups || src->total_px < 0 || src->total_px > px_bound;
+  for (int e = threadIdx.x; e < (int)(sizeof(FtnDesc) / 4); e += blockDim.x) d[e] = bad ? 0 : s[e];
+  if (threadIdx.x == 0) d[sizeof(FtnDesc) / 4] = bad ? 1 : 0;
+}
 
 // ---------------------------------------------------------------- pixel decode
 struct Px {
@@ -116,6 +131,7 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
   // every grid (x = 0 there, :1017, so a = bias).  The conv stage folds these rows into its period grids while
   // staging (ConvArgs.bt_L), which is the reference's reshape (:1041-1046) done by index arithmetic.
   const FtnDesc* __restrict__ d = a.desc;
+  if (XIN == 1 && blockIdx.x == 0 && a.guard_dst != nullptr) guard_desc(a.guard_src, a.guard_dst, a.guard_groups, a.guard_px);
   const int N = XIN == 1 ? a.B * a.L + 1 : a.B * d->total_px;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int n0 = (blockIdx.x * 4 + wave) * (16 * NPXU);
@@ -1635,7 +1651,9 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
 
 // ---------------------------------------------------------------- small elementwise stages
 // single-conv mode, stage A: a[n][CP] = zero-extended x
-__global__ void k_embed(const float* __restrict__ x, float* __restrict__ out, int B, int L, int C, int CP) {
+__global__ void k_embed(const float* __restrict__ x, float* __restrict__ out, int B, int L, int C, int CP,
+                        const FtnDesc* guard_src, FtnDesc* guard_dst, int guard_groups, int guard_px) {
+  if (blockIdx.x == 0) guard_desc(guard_src, guard_dst, guard_groups, guard_px);
   // rows n = b*L + t of the window, channels zero-padded to CP, plus one all-zero pad row n = B*L
   // (the live zero pixels t >= L of every period grid, :1017); the conv folds them (ConvArgs.bt_L)
   const int cq = CP >> 2;
@@ -2105,16 +2123,6 @@ extern "C" size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int
   return ws_layout(plan, B, L, max_groups, px_bound).total;
 }
 
-// Copies the caller's descriptor to the head of the workspace; a descriptor that exceeds the bounds the
-// workspace and the grids were sized for (more groups than max_groups, more pixels than px_bound) is
-// replaced by an empty one, which makes the call the identity y = x instead of a write past a buffer.
-__global__ void k_guard(const FtnDesc* __restrict__ src, FtnDesc* __restrict__ dst, int max_groups, int px_bound) {
-  const int* s = (const int*)src;
-  int* d = (int*)dst;
-  const bool bad = src->n_groups < 0 || src->n_groups > max_groups || src->total_px < 0 || src->total_px > px_bound;
-  for (int e = threadIdx.x; e < (int)(sizeof(FtnDesc) / 4); e += blockDim.x) d[e] = bad ? 0 : s[e];
-  if (threadIdx.x == 0) d[sizeof(FtnDesc) / 4] = bad ? 1 : 0;
-}
 
 template <int NCO>
 static int launch_conv_t(const ConvArgs& ca, dim3 grid, size_t lds, hipStream_t st) {
@@ -2332,9 +2340,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
                      const float* ln_b, float ln_eps) {
   const WsLayout wl = ws_layout(pl, B, L, max_groups, px_bound);
   const int px_row = worst_px_per_row(L, max_groups, px_bound);
-  hipLaunchKernelGGL(k_guard, dim3(1), dim3(256), 0, st, desc_in, (FtnDesc*)ws, max_groups, px_row);
-  FTN_CHECK_LAUNCH();
-  const FtnDesc* desc = (const FtnDesc*)ws;
+  const FtnDesc* desc = (const FtnDesc*)ws;     // sanitised copy, written by the first launch (stage A)
   float* bufA = (float*)(ws + wl.offA);
   float* buf0 = (float*)(ws + wl.off0);
   float* buf1 = (float*)(ws + wl.off1);
@@ -2365,6 +2371,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     PwArgs pa = {};
     pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = bufA; pa.desc = desc;
     pa.B = B; pa.L = L; pa.C = C; pa.KIN = CP; pa.n_ot = CA / 16; pa.OUTC = CA;
+    pa.guard_src = desc_in; pa.guard_dst = (FtnDesc*)ws; pa.guard_groups = max_groups; pa.guard_px = px_row;
     if (use_bf && h2) { if ((rc = launch_pw<ACT, 1, 3>(pa, xvec, nblk_pw, st))) return rc; }
     else if (use_bf) { if ((rc = launch_pw<ACT, 1, 2>(pa, xvec, nblk_pw, st))) return rc; }
     else if ((rc = launch_pw<ACT, 1, 0>(pa, xvec, nblk_pw, st))) return rc;
@@ -2487,7 +2494,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     prof_mark(5, st);
   } else {
     // A: zero-extended copy of x
-    hipLaunchKernelGGL(k_embed, dim3(nblk_ew), dim3(256), 0, st, x, bufA, B, L, C, CP);
+    hipLaunchKernelGGL(k_embed, dim3(nblk_ew), dim3(256), 0, st, x, bufA, B, L, C, CP, desc_in, (FtnDesc*)ws, max_groups, px_row);
     FTN_CHECK_LAUNCH();
     prof_mark(1, st);
     // B: m = conv_merged(x) (+ folded proj bias)
