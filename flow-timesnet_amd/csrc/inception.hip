@@ -1685,7 +1685,15 @@ struct OutArgs {
   const float* ln_g;     // optional fused epilogue (FAST path): y = LayerNorm_C(x + ((x + comb) - x)), the
   const float* ln_b;     // per-block residual + shared LayerNorm of TimesNet.forward (reference :2050-2058)
   float ln_eps;
+  int act_dtype;         // 1 bf16 / 2 fp16 input: the reference rounds every per-group delta, each weighted
+                         // term, their sum and x + sum to the input dtype (:1068-1069, :1092, :818); 0 = fp32
 };
+
+__device__ __forceinline__ f4 rnd_act4(f4 v, int act_dtype) {
+  if (act_dtype == 1) { v.x = (float)(__bf16)v.x; v.y = (float)(__bf16)v.y; v.z = (float)(__bf16)v.z; v.w = (float)(__bf16)v.w; }
+  else if (act_dtype == 2) { v.x = (float)(_Float16)v.x; v.y = (float)(_Float16)v.y; v.z = (float)(_Float16)v.z; v.w = (float)(_Float16)v.w; }
+  return v;
+}
 
 // LayerNorm over the channel axis of an MFMA D-layout tile set: v[o][u][r] is channel 16o+4q+r of the
 // pixel (u, lane&15); the four q lane-groups of a pixel are combined with two xor-shuffles.
@@ -1846,7 +1854,10 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
 #pragma unroll
       for (int o = 0; o < 4; ++o)
 #pragma unroll
-        for (int u = 0; u < NPX; ++u) yacc[o][u] += (act4<ACT>(z[o][u]) + rr[o][u]) * w[u];
+        for (int u = 0; u < NPX; ++u) {
+          if (a.act_dtype == 0) yacc[o][u] += (act4<ACT>(z[o][u]) + rr[o][u]) * w[u];
+          else yacc[o][u] += rnd_act4(rnd_act4(act4<ACT>(z[o][u]) + rr[o][u], a.act_dtype) * w[u], a.act_dtype);
+        }
 #pragma unroll
       for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -1868,7 +1879,7 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
             for (int r = 0; r < 4; ++r)
               if (ch + r < a.C) xv[r] = a.x[e0 + r];
           }
-          const f4 nv = xv + yacc[o][u];
+          const f4 nv = a.act_dtype == 0 ? xv + yacc[o][u] : rnd_act4(xv + rnd_act4(yacc[o][u], a.act_dtype), a.act_dtype);
           yacc[o][u] = ln ? xv + (nv - xv) : nv;
         }
       }
@@ -1950,7 +1961,8 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
           for (int u = 0; u < NPX; ++u) {
             const f4 r = *(const f4*)(a.R + pn[u] * CP + 16 * (og + o) + 4 * q);
             const f4 dl = act4<ACT>(z[o][u]) + r;
-            yacc[o][u] += dl * w[u];
+            if (a.act_dtype == 0) yacc[o][u] += dl * w[u];
+            else yacc[o][u] += rnd_act4(rnd_act4(dl, a.act_dtype) * w[u], a.act_dtype);
           }
         }
       }
@@ -1964,11 +1976,18 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
           const int ch = 16 * (og + o) + 4 * q;
           const size_t e0 = ((size_t)bb[u] * a.L + tt[u]) * a.C + ch;
           if (XVEC) {
-            if (ch < a.C) *(f4*)(a.y + e0) = *(const f4*)(a.x + e0) + yacc[o][u];
+            if (ch < a.C) {
+              const f4 xv = *(const f4*)(a.x + e0);
+              *(f4*)(a.y + e0) = a.act_dtype == 0 ? xv + yacc[o][u] : rnd_act4(xv + rnd_act4(yacc[o][u], a.act_dtype), a.act_dtype);
+            }
           } else {
+            const f4 sr = rnd_act4(yacc[o][u], a.act_dtype);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (ch + r < a.C) a.y[e0 + r] = a.x[e0 + r] + yacc[o][u][r];
+              if (ch + r < a.C) {
+                const float t = a.x[e0 + r] + sr[r];
+                a.y[e0 + r] = a.act_dtype == 1 ? (float)(__bf16)t : (a.act_dtype == 2 ? (float)(_Float16)t : t);
+              }
           }
         }
       }
@@ -2337,7 +2356,7 @@ static int launch_mlp_bf(const MlpBfArgs& ma, bool xvec, long long Nmax, hipStre
 template <int ACT>
 static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, const float* wb, const FtnDesc* desc_in,
                      const float* wts, int max_groups, int px_bound, char* ws, hipStream_t st, const float* ln_g,
-                     const float* ln_b, float ln_eps) {
+                     const float* ln_b, float ln_eps, int act_dtype) {
   const WsLayout wl = ws_layout(pl, B, L, max_groups, px_bound);
   const int px_row = worst_px_per_row(L, max_groups, px_bound);
   const FtnDesc* desc = (const FtnDesc*)ws;     // sanitised copy, written by the first launch (stage A)
@@ -2481,7 +2500,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // E+F: y = x + sum_g w (act(W_out2 m' + b) + r)
     OutArgs oa = {};
     oa.x = x; oa.y = y; oa.m = buf1; oa.R = bufR; oa.W = wb + pl->w_out2; oa.bias = wb + pl->b_out2; oa.wts = wts;
-    oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CA;
+    oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CA; oa.act_dtype = act_dtype;
     const bool fast = CA <= 48 && CP <= 64;
     if (fast) { oa.ln_g = ln_g; oa.ln_b = ln_b; oa.ln_eps = ln_eps; ln_g = nullptr; }   // fused epilogue
     // FAST path: 16 pixels per wave (3 waves/SIMD; with 32 the kernel needs > 256 registers -> 1 wave/SIMD)
@@ -2526,7 +2545,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // E+F: y = x + sum_g w (act(m') + r)
     OutArgs oa = {};
     oa.x = x; oa.y = y; oa.m = buf0; oa.R = bufR; oa.W = nullptr; oa.bias = nullptr; oa.wts = wts;
-    oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CP;
+    oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CP; oa.act_dtype = act_dtype;
     if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, true, false>), dim3(nblk_out), dim3(256), 0, st, oa);
     else hipLaunchKernelGGL((k_out<ACT, false, true, false>), dim3(nblk_out), dim3(256), 0, st, oa);
     FTN_CHECK_LAUNCH();
@@ -2545,7 +2564,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
 static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev, int max_groups,
                            int px_bound, void* ws_dev, size_t ws_bytes, void* stream, const float* ln_g, const float* ln_b,
-                           float ln_eps) {
+                           float ln_eps, int act_dtype) {
   FTN_CHECK_ARG(x_dev && y_dev && plan && wblob_dev && desc_dev && weights_dev && ws_dev,
                 "ftn_timesblock_forward: null pointer");
   FTN_CHECK_ARG(B >= 1 && B <= 65535 && L >= 2, "ftn_timesblock_forward: bad shape B=%d L=%d", B, L);
@@ -2557,6 +2576,8 @@ static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const
   FTN_CHECK_ARG(plan->res1 || plan->CP == plan->FP, "identity res1 needs d_model == d_ff");
   FTN_CHECK_ARG(plan->res2 || plan->CP == plan->FP, "identity res2 needs d_model == d_ff");
   FTN_CHECK_ARG(px_bound >= 0, "ftn_timesblock_forward: px_bound=%d", px_bound);
+  FTN_CHECK_ARG(act_dtype >= 0 && act_dtype <= 2 && !(act_dtype != 0 && ln_g != nullptr),
+                "ftn_timesblock_forward: act_dtype=%d (the fused LayerNorm epilogue is fp32 only)", act_dtype);
   const size_t need = ftn_timesblock_workspace_bytes(plan, B, L, max_groups, px_bound);
   FTN_CHECK_ARG(need > 0, "ftn_timesblock_forward: B*pixels per row exceeds 2^31 (B=%d L=%d)", B, L);
   FTN_CHECK_ARG(ws_bytes >= need, "ftn_timesblock_forward: workspace %zu < %zu bytes", ws_bytes, need);
@@ -2564,16 +2585,17 @@ static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const
                 "ftn_timesblock_forward: workspace/weights must be 256/16-byte aligned");
   if (plan->act == 1)
     return forward_t<1>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, (char*)ws_dev,
-                        (hipStream_t)stream, ln_g, ln_b, ln_eps);
+                        (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype);
   return forward_t<0>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, (char*)ws_dev,
-                      (hipStream_t)stream, ln_g, ln_b, ln_eps);
+                      (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype);
 }
 
 extern "C" int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                       const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                                      int max_groups, int px_bound, void* ws_dev, size_t ws_bytes, void* stream) {
+                                      int max_groups, int px_bound, int act_dtype, void* ws_dev, size_t ws_bytes,
+                                      void* stream) {
   return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, ws_dev, ws_bytes,
-                         stream, nullptr, nullptr, 0.f);
+                         stream, nullptr, nullptr, 0.f, act_dtype);
 }
 
 extern "C" int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
@@ -2583,7 +2605,7 @@ extern "C" int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int
                                            void* stream) {
   FTN_CHECK_ARG(ln_gamma_dev && ln_beta_dev && ln_eps >= 0.f, "ftn_timesblock_forward_norm: LayerNorm parameters");
   return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, ws_dev,
-                         ws_bytes, stream, ln_gamma_dev, ln_beta_dev, ln_eps);
+                         ws_bytes, stream, ln_gamma_dev, ln_beta_dev, ln_eps, 0);
 }
 
 extern "C" int ftn_residual_layernorm(const float* x_dev, const float* new_dev, float* out_dev, long long rows, int C,

@@ -338,6 +338,15 @@ extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, cons
 // ---------------------------------------------------------------- S3 - S5
 struct ArgMax { float v; int i; };
 
+// Half-precision inputs (act_dtype 1 = bf16, 2 = fp16): the reference rounds the batch-mean spectrum, the
+// scores, the returned amplitudes, the softmax weights and their per-group sums to the input dtype
+// (:124, :130, :159, :1000, :1009 scatter_add_ in that dtype); rnd() is that rounding, the identity for fp32.
+__device__ __forceinline__ float rnd_act(float v, int act_dtype) {
+  if (act_dtype == 1) return (float)(__bf16)v;
+  if (act_dtype == 2) return (float)(_Float16)v;
+  return v;
+}
+
 __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
   // larger value wins; ties -> lower index (torch.topk's tie order is
   // implementation-defined; we fix lowest-index-first)
@@ -348,7 +357,7 @@ __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psum, int nparts, int Btotal,
                                                   const float* __restrict__ med, int B, int L, int F, int kcfg,
                                                   int pmax, int min_thr, FtnDesc* __restrict__ desc,
-                                                  float* __restrict__ amps, float* __restrict__ wts) {
+                                                  float* __restrict__ amps, float* __restrict__ wts, int act_dtype) {
   extern __shared__ __attribute__((aligned(16))) float score[];  // [F]
   __shared__ int sel_idx[FTN_KMAX];
   __shared__ FtnDesc sd;
@@ -358,8 +367,8 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psu
   for (int f = tid; f < F; f += 256) {
     double s = 0.0;
     for (int p = 0; p < nparts; ++p) s += psum[(size_t)p * F + f];
-    float m = (float)(s / (double)Btotal);
-    float sc = m - 1e-8f * log1pf((float)f);
+    float m = rnd_act((float)(s / (double)Btotal), act_dtype);
+    float sc = rnd_act(m - rnd_act(1e-8f * rnd_act(log1pf((float)f), act_dtype), act_dtype), act_dtype);
     score[f] = (f == 0) ? -INFINITY : sc;
   }
   __syncthreads();
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psu
       // unconditional load from a clamped index: a guarded load compiles to load + branch + wait per candidate
       // (serialised memory round trips on this one-workgroup kernel's critical path)
       const float mv = med[(size_t)b * F + (j < nsel ? sd.sel_freq[j] : 0)];
-      a[j] = (j < nsel) ? mv : 0.f;
+      a[j] = (j < nsel) ? rnd_act(mv, act_dtype) : 0.f;
       amps[(size_t)b * FTN_KMAX + j] = a[j];
       if (j < nsel && sd.sel_group[j] >= 0) mx = fmaxf(mx, a[j]);
     }
@@ -509,10 +518,10 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psu
 #pragma unroll
     for (int j = 0; j < FTN_KMAX; ++j) {
       if (j < nsel && sd.sel_group[j] >= 0) {
-        const float s = a[j] / den;
+        const float s = rnd_act(a[j] / den, act_dtype);
         const int g = sd.sel_group[j];
 #pragma unroll
-        for (int gg = 0; gg < FTN_KMAX; ++gg) if (gg == g) w[gg] += s;
+        for (int gg = 0; gg < FTN_KMAX; ++gg) if (gg == g) w[gg] = rnd_act(w[gg] + s, act_dtype);
       }
     }
 #pragma unroll
@@ -521,11 +530,12 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psu
 }
 
 extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B,
-                                   int L, int k_periods, int pmax, int min_period_threshold, FtnDesc* desc_dev,
-                                   float* amps_dev, float* weights_dev, void* stream) {
+                                   int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
+                                   FtnDesc* desc_dev, float* amps_dev, float* weights_dev, void* stream) {
   FTN_CHECK_ARG(psum_dev && med_dev && desc_dev && amps_dev && weights_dev, "ftn_period_finalize: null pointer");
   FTN_CHECK_ARG(B >= 1 && L >= 2 && nparts >= 1 && Btotal >= B, "ftn_period_finalize: bad shape");
   FTN_CHECK_ARG(k_periods <= FTN_KMAX, "ftn_period_finalize: k_periods=%d > FTN_KMAX=%d", k_periods, FTN_KMAX);
+  FTN_CHECK_ARG(act_dtype >= 0 && act_dtype <= 2, "ftn_period_finalize: act_dtype=%d", act_dtype);
   // ctor clamps of FFTPeriodSelector (:59-62)
   if (k_periods < 0) k_periods = 0;
   if (pmax < 1) pmax = 1;
@@ -535,7 +545,7 @@ extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btota
   const size_t lds = (size_t)F * sizeof(float);
   FTN_CHECK_ARG(lds <= 48 * 1024, "ftn_period_finalize: L=%d too long", L);
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), lds, (hipStream_t)stream, psum_dev, nparts, Btotal, med_dev, B,
-                     L, F, k_periods, pmax, min_period_threshold, desc_dev, amps_dev, weights_dev);
+                     L, F, k_periods, pmax, min_period_threshold, desc_dev, amps_dev, weights_dev, act_dtype);
   FTN_CHECK_LAUNCH();
   return 0;
 }

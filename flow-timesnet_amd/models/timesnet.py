@@ -110,9 +110,11 @@ class FFTPeriodSelector(nn.Module):
         B, L, C = x.shape
         return self.k <= 0 or L <= 1 or C <= 0 or B <= 0 or min(self.pmax, max(1, L - 1)) < self.min_period_threshold
 
-    def select_device(self, x: torch.Tensor):
+    def select_device(self, x: torch.Tensor, act_dtype: Optional[torch.dtype] = None):
         """Run S1-S5 on the device; returns a ``runtime.Selection`` (or ``None`` when
-        the selector is degenerate, reference :89-90,140-142)."""
+        the selector is degenerate, reference :89-90,140-142).  ``act_dtype`` (default: ``x.dtype``) is the
+        caller's activation dtype: for bf16 / fp16 the reference's roundings of scores, amplitudes and
+        softmax weights are applied (:124-159, :1000-1009)."""
         from .. import runtime
 
         if x.ndim != 3:
@@ -124,6 +126,7 @@ class FFTPeriodSelector(nn.Module):
         if self.k > FTN_KMAX:
             raise ValueError(f"k_periods={self.k} exceeds the native limit FTN_KMAX={FTN_KMAX}")
         B, L, _ = x.shape
+        adt = runtime.ACT_DTYPE.get(act_dtype if act_dtype is not None else x.dtype, 0)
         xf = x.detach()
         if xf.dtype != torch.float32:
             xf = xf.float()                                   # FFT is always >= fp32 (:92-94)
@@ -141,7 +144,7 @@ class FFTPeriodSelector(nn.Module):
                 dist.all_gather_into_tensor(parts, psum, group=self.shard_group)
             b_total = B * world          # equal shards (no host sync to learn otherwise)
             psum = parts
-        sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold)
+        sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold, adt)
         self._pending = sel
         return sel
 
@@ -378,7 +381,7 @@ class TimesBlock(nn.Module):
         use_hip = (self._standard_inception() and not (self.training and self._dropout > 0.0)
                    and _hip_eligible(x, self.inception))
         fused = (post_norm is not None and use_hip and _affine_layernorm(post_norm, x.size(-1))
-                 and _hip_eligible(x, post_norm))
+                 and _hip_eligible(x, post_norm) and x.dtype == torch.float32)
         if not use_hip:
             self._last_backend = "torch"
             new = self._forward_torch(x)
@@ -415,8 +418,11 @@ class TimesBlock(nn.Module):
         if xf.dtype != torch.float32:
             xf = xf.float()
         xf = xf.contiguous()
+        adt = runtime.ACT_DTYPE.get(x.dtype, 0)
+        if adt != 0:
+            norm = None                        # half inputs: the shell's LayerNorm runs outside (see forward)
         if native:
-            sel = sel_mod.select_device(xf)
+            sel = sel_mod.select_device(xf, act_dtype=x.dtype)
             if sel is None:                                            # reference :796-797
                 self._last_raw_period_count = self._last_valid_period_count = self._last_group_count = 0
                 return unchanged()
@@ -439,13 +445,14 @@ class TimesBlock(nn.Module):
             self._last_group_count = int(grp.periods.numel())
             if grp.periods.numel() == 0:
                 return unchanged()
-            w = _group_weights(amps.detach().float().cpu(), grp.mapping, grp.periods.numel(), B)
+            # softmax in fp32, rounded to the amplitudes' dtype and scatter-added in it, as the reference (:1000-1009)
+            w = _group_weights(amps.detach().cpu(), grp.mapping, grp.periods.numel(), B).float()
             dh = lib.desc_from_periods(grp.periods.tolist(), L, 1, 2 ** 30)
             if int(dh.n_groups) != grp.periods.numel():
                 raise RuntimeError("host grouping and descriptor disagree")
             sel = runtime.selection_from_host(dh, w, x.device)
         wblob, plan = self._packed(x.device)
-        y = runtime.timesblock_forward(xf, plan, wblob, sel, norm)
+        y = runtime.timesblock_forward(xf, plan, wblob, sel, norm, adt)
         if _env_on("TIMESBLOCK_VEC_DISABLE"):
             # same kernels either way (the two reference paths are the same math, :866-953);
             # only the counters differ.  Reading the group count synchronises, as the reference does.
@@ -483,15 +490,16 @@ class TimesBlock(nn.Module):
             w = F.softmax(grp.logits.float(), dim=1).to(x.dtype)        # loop path (:820-864)
             self._last_loop_iterations = G
         xt = x.permute(0, 2, 1)
-        combined = None
+        deltas = []
         for g in range(G):
             p, pad, cyc = int(grp.periods[g]), int(grp.pad_lengths[g]), int(grp.cycles[g])
             grid = F.pad(xt, (0, pad)).reshape(B, C, cyc, p)
             gin = grid.float() if grid.dtype != torch.float32 else grid
             out = self.inception(gin)
-            delta = (out.float() - gin).reshape(B, C, L + pad)[..., :L].permute(0, 2, 1).to(x.dtype)
-            term = delta * w[:, g].to(x.dtype).view(B, 1, 1)
-            combined = term if combined is None else combined + term
+            deltas.append((out.float() - gin).reshape(B, C, L + pad)[..., :L].permute(0, 2, 1).to(x.dtype))
+        # stacked weighted sum in the input dtype, exactly as the reference forms it (:1075-1092)
+        stacked = torch.stack(deltas, dim=-1)
+        combined = (stacked * w.to(dtype=stacked.dtype).view(B, 1, 1, -1)).sum(dim=-1)
         return x + combined
 
 

@@ -100,9 +100,13 @@ def spectrum(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return med, psum
 
 
+ACT_DTYPE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
 def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int, pmax: int,
-             min_thr: int) -> Selection:
-    """S3-S5 on the device.  ``psum`` is [F] or [nparts, F] (multi-GPU partial sums)."""
+             min_thr: int, act_dtype: int = 0) -> Selection:
+    """S3-S5 on the device.  ``psum`` is [F] or [nparts, F] (multi-GPU partial sums); ``act_dtype`` 1 / 2
+    applies the reference's bf16 / fp16 roundings of scores, amplitudes and weights."""
     lib = _lib.load()
     B = med.shape[0]
     dev = med.device
@@ -111,7 +115,7 @@ def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int
     amps = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
     wts = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
     check(lib.ftn_period_finalize(_ptr(psum), nparts, int(b_total), _ptr(med), B, L, int(k), int(pmax),
-                                  int(min_thr), _ptr(desc), _ptr(amps), _ptr(wts), _stream(dev)),
+                                  int(min_thr), int(act_dtype), _ptr(desc), _ptr(amps), _ptr(wts), _stream(dev)),
           "ftn_period_finalize")
     mg = C.c_int(0)
     pxb = lib.ftn_selector_px_bound(L, int(k), int(pmax), int(min_thr), C.byref(mg))
@@ -136,7 +140,7 @@ def selection_from_host(desc_host: FtnDesc, weights: torch.Tensor, device: torch
 
 # ------------------------------------------------------------------ conv path
 def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel: Selection,
-                       norm=None) -> torch.Tensor:
+                       norm=None, act_dtype: int = 0) -> torch.Tensor:
     """``norm=(gamma, beta, eps)`` appends the model's per-block ``LayerNorm(x + (y - x))``
     (reference :2050-2058) to the same call."""
     lib = _lib.load()
@@ -157,7 +161,7 @@ def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel:
               "ftn_timesblock_forward_norm")
         return y
     check(lib.ftn_timesblock_forward(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
-                                     _ptr(sel.weights), sel.max_groups, sel.px_bound, _ptr(ws), ws.numel(),
+                                     _ptr(sel.weights), sel.max_groups, sel.px_bound, int(act_dtype), _ptr(ws), ws.numel(),
                                      _stream(x.device)), "ftn_timesblock_forward")
     return y
 

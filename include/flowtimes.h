@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTN_ABI_VERSION 6
+#define FTN_ABI_VERSION 7
 #define FTN_KMAX 16      /* max period candidates / groups per block call        */
 #define FTN_MAXBR 8      /* max kernels in kernel_set                             */
 
@@ -121,9 +121,13 @@ int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* tab
 /* S3-S5 (:119-157, PeriodGrouper.group :513-557, softmax/scatter :992-1009).
  * psum: [nparts][F] partial batch sums (summed in index order; nparts>1 is the
  * multi-GPU exchange of SURVEY §8e), Btotal = global batch.  Writes the
- * descriptor, amps[B][FTN_KMAX] and group weights w[B][FTN_KMAX]. */
+ * descriptor, amps[B][FTN_KMAX] and group weights w[B][FTN_KMAX].
+ * act_dtype: dtype of the caller's activations - 0 fp32, 1 bf16, 2 fp16.  For half inputs the reference
+ * rounds the batch-mean spectrum and the scores (:124, :130), the returned amplitudes (:159), the softmax
+ * weights (:1000) and their scatter-added group sums (:1009) to that dtype; the kernel applies the same
+ * roundings (the values are still delivered as fp32). */
 int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev,
-                        int B, int L, int k_periods, int pmax, int min_period_threshold,
+                        int B, int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
                         FtnDesc* desc_dev, float* amps_dev, float* weights_dev, void* stream);
 /* Host-only: PeriodGrouper.group (:513-557, env flags unset) + conv tiling for
  * periods that come from somewhere else (stub selectors in the reference tests).
@@ -146,10 +150,14 @@ int ftn_selector_px_bound(int L, int k_periods, int pmax, int min_period_thresho
  * graph beside eager calls) need their own.  Returns 0 for a shape it cannot run. */
 size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max_groups, int px_bound);
 /* y = x + sum_g w[b,g] * (inception(fold_g(x)) - fold_g(x))[:L]  (:1041-1092, :818).
- * desc/weights are device pointers. */
+ * desc/weights are device pointers.  act_dtype (0 fp32, 1 bf16, 2 fp16) = dtype of the caller's activations:
+ * x_dev / y_dev are always fp32 buffers (the caller up-casts, as the reference does for its convs, :1047-1052),
+ * and for a half dtype every per-group delta, each weighted term, their sum and x + sum are rounded to it
+ * exactly where the reference rounds them (:1068-1069, :1092, :818), so y holds values of that dtype. */
 int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                           int max_groups, int px_bound, void* ws_dev, size_t ws_bytes, void* stream);
+                           int max_groups, int px_bound, int act_dtype, void* ws_dev, size_t ws_bytes,
+                           void* stream);
 /* The same call followed by the caller's per-block epilogue of TimesNet.forward (:2050-2058, eval mode):
  *   y = LayerNorm_C( x + (block(x) - x) ; gamma, beta, eps )
  * fused into the last kernel when d_model <= 64 (bottleneck mode), one extra in-place row pass otherwise. */

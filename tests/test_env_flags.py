@@ -11,7 +11,10 @@ import torch
 
 from conftest import GOLDEN
 
-ENV_CASES = json.loads((GOLDEN / "manifest_env.json").read_text())["cases"]
+_ALL = json.loads((GOLDEN / "manifest_env.json").read_text())["cases"]
+ENV_CASES = {k: v for k, v in _ALL.items() if v["kind"] != "half"}
+HALF_CASES = {k: v for k, v in _ALL.items() if v["kind"] == "half"}
+DT = {"bfloat16": torch.bfloat16, "float16": torch.float16}
 HYP = json.loads((GOLDEN / "manifest.json").read_text())["hypers"]
 FLAGS = ("TIMES_PERIOD_MAX_UNIQ", "TIMES_PERIOD_BINNING", "TIMESBLOCK_VEC_DISABLE")
 
@@ -139,7 +142,50 @@ def test_log_binning_parser_cases(raw, want, ftn):
     assert grouping._resolve_log_binning_base(raw, None) == want
 
 
+# ---- half-precision inputs: the reference rounds amplitudes, softmax weights, every per-group delta, the weighted
+#      terms' sum and x + sum to the input dtype (:124-159, :1000-1009, :1068-1069, :1092, :818)
+def _half_block(ftn, case, g, device):
+    blk = _block(ftn, case, device)
+    if case["K"]:
+        blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(case["K"], case["L"])
+    else:
+        object.__setattr__(blk, "period_selector", _Stub(g["periods"], g["amps"]))
+    return blk
+
+
+@pytest.mark.parametrize("name", sorted(HALF_CASES))
+def test_mirror_block_half_input_matches_reference_bitwise(name, ftn):
+    case, g = HALF_CASES[name], _load(name)
+    blk = _half_block(ftn, case, g, "cpu")
+    with torch.no_grad():
+        y = blk(torch.from_numpy(g["x"]).to(DT[case["dtype"]]))
+    assert y.dtype == DT[case["dtype"]] and blk._last_group_count == case["groups"]
+    assert next(blk.inception.parameters()).dtype == torch.float32
+    np.testing.assert_array_equal(y.float().numpy(), g["y"])
+
+
 # ------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["f16x2", "f32"])
+@pytest.mark.parametrize("name", sorted(HALF_CASES))
+def test_hip_block_half_input_matches_reference(name, engine, ftn):
+    """The HIP path with bf16 / fp16 activations: same rounding points as the reference, so the output agrees
+    with the reference's own half-precision output to one unit in the last place of that dtype (the fp32 conv
+    results under the roundings differ at the 1e-6 level, which can flip a rounding)."""
+    dev = torch.device("cuda:0")
+    case, g = HALF_CASES[name], _load(name)
+    dt = DT[case["dtype"]]
+    blk = _half_block(ftn, case, g, dev)
+    blk.engine = engine
+    with torch.inference_mode():
+        y = blk(torch.from_numpy(g["x"]).to(dt).to(dev))
+    assert blk._last_backend == "hip" and y.dtype == dt and blk._last_group_count == case["groups"]
+    if case["K"]:
+        assert blk.period_selector.last_selected_periods.tolist() == g["periods"].tolist()
+    got, want = y.float().cpu().numpy(), g["y"]
+    ulp = np.abs(want) * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) + 1e-30
+    assert np.all(np.abs(got - want) <= 1.001 * ulp), float(np.max(np.abs(got - want) / ulp))
+    assert np.mean(got == want) > 0.97
 @pytest.mark.gpu
 @pytest.mark.parametrize("engine", ["f16x2", "f32"])
 @pytest.mark.parametrize("name", sorted(ENV_CASES))

@@ -115,8 +115,8 @@ def test_c4_model_shard(ftn, dev):
     sel = gpu.period_selector
     orig = sel.select_device
 
-    def recording(t):
-        s = orig(t)
+    def recording(t, **kw):
+        s = orig(t, **kw)
         recs.append(s)
         return s
 
@@ -246,7 +246,7 @@ def test_descriptor_beyond_declared_bounds_is_identity(ftn, dev):
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         y = torch.full_like(x, float("nan"))
         ftn.lib.check(lib.ftn_timesblock_forward(x.data_ptr(), y.data_ptr(), B, L, ctypes.byref(plan),
-                                                 wblob.data_ptr(), sel.desc.data_ptr(), sel.weights.data_ptr(), mg, pxb,
+                                                 wblob.data_ptr(), sel.desc.data_ptr(), sel.weights.data_ptr(), mg, pxb, 0,
                                                  ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
                       "ftn_timesblock_forward")
         torch.cuda.synchronize()
