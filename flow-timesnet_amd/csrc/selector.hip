@@ -357,10 +357,14 @@ __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psum, int nparts, int Btotal,
                                                   const float* __restrict__ med, int B, int L, int F, int kcfg,
                                                   int pmax, int min_thr, FtnDesc* __restrict__ desc,
-                                                  float* __restrict__ amps, float* __restrict__ wts, int act_dtype) {
+                                                  float* __restrict__ amps, float* __restrict__ wts, int act_dtype,
+                                                  int max_unique, float log_base) {
   extern __shared__ __attribute__((aligned(16))) float score[];  // [F]
   __shared__ int sel_idx[FTN_KMAX];
   __shared__ FtnDesc sd;
+  __shared__ float red[256][FTN_KMAX + 1];                        // block reductions of the flagged grouping
+  __shared__ float colmean[FTN_KMAX], gscore[FTN_KMAX];
+  __shared__ int c_assign[FTN_KMAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   // mean over the (global) batch, DC kill, log penalty          (:112-130)
@@ -488,6 +492,167 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psu
     if (lane == FTN_KMAX) { sd.total_px = opx; sd.tiles_per_row = otl; }
   }
   __syncthreads();
+  // ---- TIMES_PERIOD_BINNING / TIMES_PERIOD_MAX_UNIQ (reference :350-437; resolved per block depth on the host and
+  //      passed in): candidates are grouped by log bucket instead of by period, and / or only the `max_unique`
+  //      groups with the largest batch-mean logsumexp survive, the others joining the kept group of nearest
+  //      period.  A group's period is its member with the largest batch-mean amplitude.  Needs two reductions
+  //      over the batch (column means, group scores), done in a fixed order; the small-K logic runs on thread 0.
+  if (max_unique > 0 || log_base > 1.0f) {
+    const int nsel = sd.n_sel;
+    float part[FTN_KMAX];
+#pragma unroll
+    for (int j = 0; j < FTN_KMAX; ++j) part[j] = 0.f;
+    for (int b = tid; b < B; b += 256)
+#pragma unroll
+      for (int j = 0; j < FTN_KMAX; ++j)
+        if (j < nsel) part[j] += rnd_act(med[(size_t)b * F + sd.sel_freq[j]], act_dtype);
+#pragma unroll
+    for (int j = 0; j < FTN_KMAX; ++j) red[tid][j] = part[j];
+    __syncthreads();
+    if (tid < FTN_KMAX) {
+      float t = 0.f;
+      for (int r = 0; r < 256; ++r) t += red[r][tid];
+      colmean[tid] = rnd_act(t / (float)B, act_dtype);
+    }
+    __syncthreads();
+    // validity of every kept candidate under the grouper's filter (:517-543), initial assignment by key (:547-551)
+    if (tid == 0) {
+      int key[FTN_KMAX];
+      for (int j = 0; j < FTN_KMAX; ++j) c_assign[j] = -1;
+      for (int j = 0; j < nsel; ++j) {
+        const int p = sd.sel_period[j];
+        bool ok = p > 0 && p >= min_thr && p <= pmax;
+        if (ok) { const int pad = (p - (L % p)) % p; ok = (L + pad) / p >= 2; }
+        key[j] = !ok ? -1 : (log_base > 1.0f ? (int)floorf(logf((float)p) / logf(log_base) + 1e-6f) : p);   // :350-354
+        if (!ok) continue;
+        // assignment id = rank of the key among the distinct keys (sorted ascending), filled below
+      }
+      for (int j = 0; j < nsel; ++j) {
+        if (key[j] < 0) continue;
+        int rank = 0;
+        for (int i = 0; i < nsel; ++i) {
+          if (key[i] < 0 || key[i] >= key[j]) continue;
+          bool firstocc = true;
+          for (int h = 0; h < i; ++h) if (key[h] == key[i]) firstocc = false;
+          if (firstocc) ++rank;
+        }
+        c_assign[j] = rank;
+      }
+    }
+    __syncthreads();
+    int ngroups = 0;
+    for (int j = 0; j < nsel; ++j) if (c_assign[j] + 1 > ngroups) ngroups = c_assign[j] + 1;
+    if (max_unique > 0 && ngroups > max_unique) {
+      // group scores = batch mean of logsumexp over the members' amplitudes (:373, :386)
+      float ps[FTN_KMAX];
+#pragma unroll
+      for (int g = 0; g < FTN_KMAX; ++g) ps[g] = 0.f;
+      for (int b = tid; b < B; b += 256) {
+        float a[FTN_KMAX];
+#pragma unroll
+        for (int j = 0; j < FTN_KMAX; ++j) a[j] = j < nsel ? rnd_act(med[(size_t)b * F + sd.sel_freq[j]], act_dtype) : 0.f;
+        for (int g = 0; g < ngroups; ++g) {
+          float mx = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < FTN_KMAX; ++j) if (j < nsel && c_assign[j] == g) mx = fmaxf(mx, a[j]);
+          float se = 0.f;
+#pragma unroll
+          for (int j = 0; j < FTN_KMAX; ++j) if (j < nsel && c_assign[j] == g) se += expf(a[j] - mx);
+          ps[g] += rnd_act(logf(se) + mx, act_dtype);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < FTN_KMAX; ++g) red[tid][g] = ps[g];
+      __syncthreads();
+      if (tid < FTN_KMAX) {
+        float t = 0.f;
+        for (int r = 0; r < 256; ++r) t += red[r][tid];
+        gscore[tid] = rnd_act(t / (float)B, act_dtype);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        // canonical period of each group = member with the largest column mean (first on ties, :374-378)
+        int gper[FTN_KMAX], keep[FTN_KMAX];
+        bool kept[FTN_KMAX];
+        for (int g = 0; g < ngroups; ++g) {
+          int best = -1;
+          for (int j = 0; j < nsel; ++j)
+            if (c_assign[j] == g && (best < 0 || colmean[j] > colmean[best])) best = j;
+          gper[g] = sd.sel_period[best];
+          kept[g] = false;
+        }
+        for (int r = 0; r < max_unique; ++r) {                    // top-k by score, descending, lowest id on ties
+          int best = -1;
+          for (int g = 0; g < ngroups; ++g)
+            if (!kept[g] && (best < 0 || gscore[g] > gscore[best])) best = g;
+          keep[r] = best; kept[best] = true;
+        }
+        int target[FTN_KMAX];
+        for (int g = 0; g < ngroups; ++g) {
+          target[g] = g;
+          if (kept[g]) continue;
+          int bt = 0;
+          float bd = fabsf((float)gper[keep[0]] - (float)gper[g]);
+          for (int r = 1; r < max_unique; ++r) {                  // nearest kept period, first in keep order (:421-424)
+            const float dd = fabsf((float)gper[keep[r]] - (float)gper[g]);
+            if (dd < bd) { bd = dd; bt = r; }
+          }
+          target[g] = keep[bt];
+        }
+        for (int j = 0; j < nsel; ++j) if (c_assign[j] >= 0) c_assign[j] = target[c_assign[j]];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      // final metadata (:439-511): group period = canonical member, groups ordered by (period, canonical index)
+      int gid[FTN_KMAX], gcan[FTN_KMAX], G = 0;
+      for (int j = 0; j < nsel; ++j) {
+        if (c_assign[j] < 0) continue;
+        bool seen = false;
+        for (int g = 0; g < G; ++g) if (gid[g] == c_assign[j]) seen = true;
+        if (!seen) gid[G++] = c_assign[j];
+      }
+      for (int g = 0; g < G; ++g) {
+        int best = -1;
+        for (int j = 0; j < nsel; ++j)
+          if (c_assign[j] == gid[g] && (best < 0 || colmean[j] > colmean[best])) best = j;
+        gcan[g] = best;
+      }
+      for (int a_ = 1; a_ < G; ++a_) {                            // insertion sort by (period, canonical index)
+        const int vg = gid[a_], vc = gcan[a_];
+        int b_ = a_ - 1;
+        while (b_ >= 0 && (sd.sel_period[gcan[b_]] > sd.sel_period[vc] ||
+                           (sd.sel_period[gcan[b_]] == sd.sel_period[vc] && gcan[b_] > vc))) {
+          gid[b_ + 1] = gid[b_]; gcan[b_ + 1] = gcan[b_]; --b_;
+        }
+        gid[b_ + 1] = vg; gcan[b_ + 1] = vc;
+      }
+      int px = 0, tiles = 0;
+      for (int g = 0; g < FTN_KMAX; ++g) {
+        if (g < G) {
+          const int p = sd.sel_period[gcan[g]];
+          const int pad = (p - (L % p)) % p;
+          sd.g_period[g] = p; sd.g_pad[g] = pad; sd.g_cycles[g] = (L + pad) / p;
+          sd.g_px_off[g] = px; px += L + pad;
+          ftn_tile_geometry(sd.g_cycles[g], p, &sd.g_tw[g], &sd.g_th[g], &sd.g_ntx[g], &sd.g_nty[g]);
+          sd.g_tile_off[g] = tiles; tiles += sd.g_ntx[g] * sd.g_nty[g];
+        } else {
+          sd.g_period[g] = 0; sd.g_pad[g] = 0; sd.g_cycles[g] = 0;
+          sd.g_tw[g] = 0; sd.g_th[g] = 0; sd.g_ntx[g] = 0; sd.g_nty[g] = 0;
+          sd.g_px_off[g] = px; sd.g_tile_off[g] = tiles;
+        }
+      }
+      sd.g_px_off[FTN_KMAX] = px; sd.g_tile_off[FTN_KMAX] = tiles;
+      for (int j = 0; j < FTN_KMAX; ++j) {
+        int m = -1;
+        if (j < nsel && c_assign[j] >= 0)
+          for (int g = 0; g < G; ++g) if (gid[g] == c_assign[j]) m = g;
+        sd.sel_group[j] = m;
+      }
+      sd.n_groups = G; sd.total_px = px; sd.tiles_per_row = tiles;
+    }
+    __syncthreads();
+  }
   // write the descriptor (whole struct, cooperatively)
   {
     const int* src = (const int*)&sd;
@@ -531,7 +696,8 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psu
 
 extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B,
                                    int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
-                                   FtnDesc* desc_dev, float* amps_dev, float* weights_dev, void* stream) {
+                                   int max_unique, float log_base, FtnDesc* desc_dev, float* amps_dev,
+                                   float* weights_dev, void* stream) {
   FTN_CHECK_ARG(psum_dev && med_dev && desc_dev && amps_dev && weights_dev, "ftn_period_finalize: null pointer");
   FTN_CHECK_ARG(B >= 1 && L >= 2 && nparts >= 1 && Btotal >= B, "ftn_period_finalize: bad shape");
   FTN_CHECK_ARG(k_periods <= FTN_KMAX, "ftn_period_finalize: k_periods=%d > FTN_KMAX=%d", k_periods, FTN_KMAX);
@@ -545,7 +711,8 @@ extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btota
   const size_t lds = (size_t)F * sizeof(float);
   FTN_CHECK_ARG(lds <= 48 * 1024, "ftn_period_finalize: L=%d too long", L);
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), lds, (hipStream_t)stream, psum_dev, nparts, Btotal, med_dev, B,
-                     L, F, k_periods, pmax, min_period_threshold, desc_dev, amps_dev, weights_dev, act_dtype);
+                     L, F, k_periods, pmax, min_period_threshold, desc_dev, amps_dev, weights_dev, act_dtype,
+                     max_unique > 0 ? max_unique : 0, log_base > 1.0f ? log_base : 0.f);
   FTN_CHECK_LAUNCH();
   return 0;
 }

@@ -77,7 +77,7 @@ _SIGNATURES = {
     "ftn_dft_table_init": (C.c_int, [_P, C.c_int, _P]),
     "ftn_period_spectrum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ftn_period_finalize": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      _P, _P, _P, _P]),
+                                      C.c_int, C.c_float, _P, _P, _P, _P]),
     "ftn_desc_from_periods": (C.c_int, [C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(FtnDesc)]),
     "ftn_selector_px_bound": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),

@@ -110,7 +110,8 @@ class FFTPeriodSelector(nn.Module):
         B, L, C = x.shape
         return self.k <= 0 or L <= 1 or C <= 0 or B <= 0 or min(self.pmax, max(1, L - 1)) < self.min_period_threshold
 
-    def select_device(self, x: torch.Tensor, act_dtype: Optional[torch.dtype] = None):
+    def select_device(self, x: torch.Tensor, act_dtype: Optional[torch.dtype] = None,
+                      max_unique: Optional[int] = None, log_base: Optional[float] = None):
         """Run S1-S5 on the device; returns a ``runtime.Selection`` (or ``None`` when
         the selector is degenerate, reference :89-90,140-142).  ``act_dtype`` (default: ``x.dtype``) is the
         caller's activation dtype: for bf16 / fp16 the reference's roundings of scores, amplitudes and
@@ -144,7 +145,8 @@ class FFTPeriodSelector(nn.Module):
                 dist.all_gather_into_tensor(parts, psum, group=self.shard_group)
             b_total = B * world          # equal shards (no host sync to learn otherwise)
             psum = parts
-        sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold, adt)
+        sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold, adt,
+                               max_unique or 0, log_base or 0.0)
         self._pending = sel
         return sel
 
@@ -412,8 +414,12 @@ class TimesBlock(nn.Module):
 
         B, L, _ = x.shape
         sel_mod = self.period_selector
-        native = (type(sel_mod) is FFTPeriodSelector and not os.getenv("TIMES_PERIOD_MAX_UNIQ")
-                  and not os.getenv("TIMES_PERIOD_BINNING"))
+        native = type(sel_mod) is FFTPeriodSelector
+        # TIMES_PERIOD_MAX_UNIQ / TIMES_PERIOD_BINNING (per-depth schedules resolved here, :320-325) are grouping
+        # variants of the device finalize kernel: no host round trip on the native path
+        from ..grouping import _resolve_log_binning_base, _resolve_scheduled_int
+        max_unique = _resolve_scheduled_int(os.getenv("TIMES_PERIOD_MAX_UNIQ"), self.block_index)
+        log_base = _resolve_log_binning_base(os.getenv("TIMES_PERIOD_BINNING"), self.block_index)
         xf = x.detach()
         if xf.dtype != torch.float32:
             xf = xf.float()
@@ -422,7 +428,7 @@ class TimesBlock(nn.Module):
         if adt != 0:
             norm = None                        # half inputs: the shell's LayerNorm runs outside (see forward)
         if native:
-            sel = sel_mod.select_device(xf, act_dtype=x.dtype)
+            sel = sel_mod.select_device(xf, act_dtype=x.dtype, max_unique=max_unique, log_base=log_base)
             if sel is None:                                            # reference :796-797
                 self._last_raw_period_count = self._last_valid_period_count = self._last_group_count = 0
                 return unchanged()

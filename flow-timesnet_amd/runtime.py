@@ -104,7 +104,7 @@ ACT_DTYPE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
 
 def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int, pmax: int,
-             min_thr: int, act_dtype: int = 0) -> Selection:
+             min_thr: int, act_dtype: int = 0, max_unique: int = 0, log_base: float = 0.0) -> Selection:
     """S3-S5 on the device.  ``psum`` is [F] or [nparts, F] (multi-GPU partial sums); ``act_dtype`` 1 / 2
     applies the reference's bf16 / fp16 roundings of scores, amplitudes and weights."""
     lib = _lib.load()
@@ -115,7 +115,8 @@ def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int
     amps = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
     wts = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
     check(lib.ftn_period_finalize(_ptr(psum), nparts, int(b_total), _ptr(med), B, L, int(k), int(pmax),
-                                  int(min_thr), int(act_dtype), _ptr(desc), _ptr(amps), _ptr(wts), _stream(dev)),
+                                  int(min_thr), int(act_dtype), int(max_unique or 0), float(log_base or 0.0), _ptr(desc),
+                                  _ptr(amps), _ptr(wts), _stream(dev)),
           "ftn_period_finalize")
     mg = C.c_int(0)
     pxb = lib.ftn_selector_px_bound(L, int(k), int(pmax), int(min_thr), C.byref(mg))

@@ -125,10 +125,14 @@ int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* tab
  * act_dtype: dtype of the caller's activations - 0 fp32, 1 bf16, 2 fp16.  For half inputs the reference
  * rounds the batch-mean spectrum and the scores (:124, :130), the returned amplitudes (:159), the softmax
  * weights (:1000) and their scatter-added group sums (:1009) to that dtype; the kernel applies the same
- * roundings (the values are still delivered as fp32). */
+ * roundings (the values are still delivered as fp32).
+ * max_unique / log_base: the reference's TIMES_PERIOD_MAX_UNIQ / TIMES_PERIOD_BINNING grouping variants
+ * (:350-437) with the per-depth schedule already resolved by the caller; 0 / 0.f = unset (plain
+ * duplicate-merge grouping). */
 int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev,
                         int B, int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
-                        FtnDesc* desc_dev, float* amps_dev, float* weights_dev, void* stream);
+                        int max_unique, float log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
+                        void* stream);
 /* Host-only: PeriodGrouper.group (:513-557, env flags unset) + conv tiling for
  * periods that come from somewhere else (stub selectors in the reference tests).
  * `periods` is a host array; `desc_host` is filled on the host. */

@@ -205,4 +205,12 @@ def test_hip_block_matches_reference_under_flags(name, engine, ftn, monkeypatch)
         y = blk(torch.from_numpy(g["x"]).to(dev))
     assert blk._last_backend == "hip"
     assert blk._last_group_count == case["groups"] and blk._last_loop_iterations == case["loop_iterations"]
+    if case["kind"] == "env_native":
+        # native selector: the flagged grouping ran in the device finalize kernel (no host grouping round trip) and
+        # the descriptor it wrote equals what the reference's PeriodGrouper returned under the same flags
+        d = blk.period_selector._pending.host()
+        G, n = int(d.n_groups), int(d.n_sel)
+        assert list(d.sel_period[:n]) == g["periods"].tolist()
+        assert list(d.g_period[:G]) == g["g_periods"].tolist() and list(d.g_pad[:G]) == g["g_pad"].tolist()
+        assert list(d.g_cycles[:G]) == g["g_cycles"].tolist() and list(d.sel_group[:n]) == g["mapping"].tolist()
     np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=1e-4, atol=2e-5)
