@@ -68,11 +68,26 @@ class FtnPlan(C.Structure):
     ]
 
 
+class FtnInceptionBlockWeights(C.Structure):
+    """Mirror of ``struct FtnInceptionBlockWeights`` (include/flowtimes.h): raw host pointers to the reference
+    ``state_dict`` tensors of one InceptionBlock."""
+
+    _fields_ = [
+        ("branch_w", (C.c_void_p * 3) * FTN_MAXBR), ("branch_b", (C.c_void_p * 3) * FTN_MAXBR),
+        ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("res_w", C.c_void_p), ("res_b", C.c_void_p),
+    ]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)            -- one entry per declaration in flowtimes.h
     "ftn_abi_version": (C.c_int, []),
     "ftn_last_error": (C.c_char_p, []),
+    "ftn_inception_pack_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                              C.c_double, C.c_int]),
+    "ftn_inception_pack_weights": (C.c_int, [C.POINTER(FtnInceptionBlockWeights), C.POINTER(FtnInceptionBlockWeights),
+                                             C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                             C.c_double, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(FtnPlan)]),
     "ftn_dft_table_bytes": (C.c_size_t, [C.c_int]),
     "ftn_dft_table_init": (C.c_int, [_P, C.c_int, _P]),
     "ftn_period_spectrum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

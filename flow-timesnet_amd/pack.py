@@ -291,7 +291,69 @@ def pack_inception(
     sd: Dict[str, np.ndarray], d_model: int, d_ff: int, kernel_set: Sequence[Tuple[int, int]],
     ratio: float, act: str, engine: str | None = None,
 ) -> Tuple[np.ndarray, FtnPlan]:
-    """Fold + pack; returns (fp32 weight blob, FtnPlan with float offsets)."""
+    """Fold + pack the reference ``state_dict`` of ``TimesBlock.inception`` through the C ABI
+    (``ftn_inception_pack_weights``, csrc/pack.hip): returns (fp32 weight blob, FtnPlan with float offsets).
+    This wrapper only marshals the tensors into ``FtnInceptionBlockWeights``."""
+    import ctypes as C
+
+    from . import lib as _lib
+    from .lib import FtnInceptionBlockWeights
+
+    ks = synth.parse_kernel_set(kernel_set)
+    _check_odd(ks)
+    if len(ks) > FTN_MAXBR:
+        raise ValueError(f"at most {FTN_MAXBR} kernels are supported, got {len(ks)}")
+    eng = ENGINES[engine if engine is not None else default_engine()]
+    lib = _lib.load()
+    keep = []                                   # the fp32 arrays the C struct points into
+
+    def ptr(key):
+        if key not in sd:
+            return None
+        a = np.ascontiguousarray(np.asarray(sd[key], dtype=np.float32))
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    mid = synth.bottleneck_mid(int(d_model), int(d_ff), ratio)
+    blocks = []
+    for blk, (cin, cout) in (("0", (d_model, d_ff)), ("2", (d_ff, d_model))):
+        w = FtnInceptionBlockWeights()
+        for j, (kh, kw) in enumerate(ks):
+            for i in range(3 if mid is not None else 1):
+                key = f"{blk}.paths.{j}.branch.{i}"
+                if f"{key}.weight" not in sd:
+                    raise ValueError(f"{key}.weight missing")
+                shape = tuple(np.asarray(sd[f"{key}.weight"]).shape)
+                want = ((mid, cin, 1, 1), (mid, mid, kh, kw), (cout, mid, 1, 1))[i] if mid is not None else (cout, cin, kh, kw)
+                if shape != want:
+                    raise ValueError(f"unexpected shape {shape} of {key}.weight, expected {want}")
+                w.branch_w[j][i] = ptr(f"{key}.weight")
+                w.branch_b[j][i] = ptr(f"{key}.bias")
+        w.proj_w, w.proj_b = ptr(f"{blk}.proj.weight"), ptr(f"{blk}.proj.bias")
+        w.res_w, w.res_b = ptr(f"{blk}.res_proj.weight"), ptr(f"{blk}.res_proj.bias")
+        if w.res_w is None and cin != cout:
+            raise ValueError(f"{blk}.res_proj.weight missing although in_ch != out_ch")
+        blocks.append(w)
+    kh = (C.c_int * len(ks))(*[k[0] for k in ks])
+    kw = (C.c_int * len(ks))(*[k[1] for k in ks])
+    n = lib.ftn_inception_pack_floats(int(d_model), int(d_ff), len(ks), kh, kw, float(ratio), eng)
+    if n == 0:
+        _lib.check(-1, "ftn_inception_pack_floats")
+    blob = np.empty(n, dtype=np.float32)
+    plan = FtnPlan()
+    _lib.check(lib.ftn_inception_pack_weights(C.byref(blocks[0]), C.byref(blocks[1]), int(d_model), int(d_ff), len(ks),
+                                              kh, kw, float(ratio), 1 if act.lower() == "relu" else 0, eng,
+                                              blob.ctypes.data_as(C.c_void_p), n, C.byref(plan)),
+               "ftn_inception_pack_weights")
+    return blob, plan
+
+
+def pack_inception_numpy(
+    sd: Dict[str, np.ndarray], d_model: int, d_ff: int, kernel_set: Sequence[Tuple[int, int]],
+    ratio: float, act: str, engine: str | None = None,
+) -> Tuple[np.ndarray, FtnPlan]:
+    """The same folding + packing in numpy (round 1's packer): kept as an independent restatement that
+    ``tests/test_host_logic.py`` compares the C packer against; the product calls ``pack_inception``."""
     ks = synth.parse_kernel_set(kernel_set)
     _check_odd(ks)
     if len(ks) > FTN_MAXBR:
@@ -306,6 +368,9 @@ def pack_inception(
     mid = synth.bottleneck_mid(C, F, ratio)
     blob = _Blob()
     nk = len(ks)
+    for j in range(FTN_MAXBR):
+        plan.sc_conv1[j] = plan.sc_conv2[j] = 1.0
+    plan.sc_out1 = plan.sc_res1 = plan.sc_a2 = plan.sc_r2 = 1.0
 
     def res(blk, cin, cout, cinP, coutP):
         key = f"{blk}.res_proj.weight"

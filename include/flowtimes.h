@@ -52,7 +52,7 @@ typedef struct FtnDesc {
 } FtnDesc;
 
 /* Host-side description of one TimesBlock's (folded, packed) inception weights.
- * Filled by the host packer (flow-timesnet_amd/pack.py); offsets are in floats
+ * Filled by ftn_inception_pack_weights (host); offsets are in floats
  * into the weight blob.  Replaces nn.Sequential(InceptionBlock, act,
  * InceptionBlock) (:744-762) for inference. */
 typedef struct FtnPlan {
@@ -108,6 +108,31 @@ typedef struct FtnPlan {
 
 int ftn_abi_version(void);
 const char* ftn_last_error(void);
+
+/* ---- weight folding + packing (host only): replaces nn.Sequential(InceptionBlock, act, InceptionBlock) ---- */
+/* The reference state_dict tensors of ONE InceptionBlock (:622-637) as raw host pointers (fp32, contiguous):
+ * paths.{j}.branch.{i}.{weight,bias} - bottleneck branches (:581-590): i = 0 [mid][in][1][1], 1 [mid][mid][kh][kw],
+ * 2 [out][mid][1][1]; single-conv branches (ratio 1, :575-580): only i = 0, [out][in][kh][kw] - proj.{weight,bias}
+ * [out][out*nk][1][1], res_proj.{weight,bias} [out][in][1][1] or NULL when in == out (nn.Identity, :637). */
+typedef struct FtnInceptionBlockWeights {
+  const float* branch_w[FTN_MAXBR][3];
+  const float* branch_b[FTN_MAXBR][3];
+  const float* proj_w;
+  const float* proj_b;
+  const float* res_w;
+  const float* res_b;
+} FtnInceptionBlockWeights;
+/* floats of the packed blob for this shape (0 = bad argument); engine as FtnPlan.engine */
+size_t ftn_inception_pack_floats(int d_model, int d_ff, int n_kernels, const int* kh, const int* kw,
+                                 double bottleneck_ratio, int engine);
+/* Folds proj into every branch (fp64), pads channels to 16, lays the matrices out as MFMA fragments and, for the
+ * split engines, splits them into pieces; writes the blob (host memory, to be copied to the device 16-byte
+ * aligned) and fills *plan_out.  block0 = inception[0] (d_model -> d_ff), block2 = inception[2] (d_ff -> d_model),
+ * act 0 = GELU, 1 = ReLU.  flow-timesnet_amd/pack.py is a thin wrapper of this call. */
+int ftn_inception_pack_weights(const FtnInceptionBlockWeights* block0, const FtnInceptionBlockWeights* block2,
+                               int d_model, int d_ff, int n_kernels, const int* kh, const int* kw,
+                               double bottleneck_ratio, int act, int engine, float* blob_host, size_t blob_floats,
+                               FtnPlan* plan_out);
 
 /* ---- period selector: FFTPeriodSelector.forward (:64-159) ------------------- */
 /* bytes of the DFT twiddle table for window length L */

@@ -340,3 +340,42 @@ def test_selector_px_bound_covers_every_selectable_descriptor(ftn, L, k, pmax, t
         periods = [p for p in periods if hi >= lo and (L + p - 1) // p >= 2]
         d = ftn.lib.desc_from_periods(periods, L, lo, pmax)
         assert d.total_px <= bound and d.n_groups <= mg.value
+
+
+@pytest.mark.parametrize("engine", ["f32", "bf16x3", "f16x2", "bf16"])
+@pytest.mark.parametrize("C,d_ff,ratio,ks,act", [
+    (64, 256, 4.0, [(3, 3), (5, 5), (7, 7)], "gelu"), (16, 16, 1.0, [(3, 3)], "gelu"), (24, 48, 2.0, [(3, 5), (5, 1)], "relu"),
+    (8, 16, 1.0, [(3, 3), (5, 5)], "gelu"), (128, 512, 4.0, [(3, 3), (5, 5), (7, 7)], "gelu"), (40, 40, 4.0, [(3, 3), (5, 5)], "gelu"),
+    (192, 768, 4.0, [(3, 3), (5, 5), (7, 7)], "gelu"),
+])
+def test_c_packer_matches_numpy_packer(C, d_ff, ratio, ks, act, engine, ftn):
+    """ftn_inception_pack_weights (C ABI, csrc/pack.hip) against the independent numpy restatement: identical plan
+    (every offset, flag, scale) and the same blob - fp32 sections to fp64-folding round-off, 16-bit piece sections
+    compared as the values the pieces reconstruct."""
+    sd = ftn.synth.make_inception_params(C, d_ff, ks, ratio, 3)
+    blob_c, plan_c = ftn.pack.pack_inception(sd, C, d_ff, ks, ratio, act, engine)
+    blob_n, plan_n = ftn.pack.pack_inception_numpy(sd, C, d_ff, ks, ratio, act, engine)
+    for name, _ in ftn.lib.FtnPlan._fields_:
+        a, b = getattr(plan_c, name), getattr(plan_n, name)
+        assert (list(a) == list(b)) if hasattr(a, "__len__") else (a == b), name
+    assert blob_c.shape == blob_n.shape
+    # the 16-bit sections: fp32 words whose halves are independent bf16 / fp16 patterns
+    sixteen = np.zeros(blob_c.size, bool)
+    if plan_c.mode == 0:
+        offs = sorted(set([plan_c.total_floats, plan_c.b_conv1s or plan_c.total_floats, plan_c.b_out1s or plan_c.total_floats] +
+                          list(plan_c.w_convbf1[:plan_c.nbr]) + list(plan_c.w_convbf2[:plan_c.nbr]) +
+                          ([plan_c.w_cfragbf] if plan_c.cfragbf_per_chunk else [])))
+        starts = set(list(plan_c.w_convbf1[:plan_c.nbr]) + list(plan_c.w_convbf2[:plan_c.nbr]) +
+                     ([plan_c.w_cfragbf] if plan_c.cfragbf_per_chunk else []))
+        for lo, hi in zip(offs[:-1], offs[1:]):
+            if lo in starts:
+                sixteen[lo:hi] = True
+    np.testing.assert_allclose(blob_c[~sixteen], blob_n[~sixteen], rtol=2e-6, atol=1e-9)
+    if sixteen.any():
+        dec = (lambda u: u.view(np.float16).astype(np.float64)) if engine == "f16x2" else \
+              (lambda u: (u.astype(np.uint32) << 16).view(np.float32).astype(np.float64))
+        pc, pn = dec(blob_c[sixteen].view(np.uint16)), dec(blob_n[sixteen].view(np.uint16))
+        # a hi piece may round the other way when the fp64 fold differs in the last bit; the sum of a fragment's
+        # pieces (what the kernels effectively multiply by) must agree
+        assert np.mean(pc == pn) > 0.995
+        np.testing.assert_allclose(pc, pn, rtol=1e-2, atol=1e-6)
