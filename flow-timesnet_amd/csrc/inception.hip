@@ -1209,6 +1209,7 @@ struct ConvBfArgs {
   int kh[FTN_MAXBR], kw[FTN_MAXBR], order[FTN_MAXBR];
   int bt_L;              // as ConvArgs.bt_L: > 0 = input rows per window position + one pad row
   float inv[FTN_MAXBR];  // f16x2: 2^-s of the branch's prescaled weights (applied to the accumulators)
+  int wg_off[FTN_MAXBR + 1];   // k_conv_bf_fast: workgroups [wg_off[k], wg_off[k+1]) serve branch k
   unsigned long long* dbg; size_t dbg_cap;
 };
 
@@ -1528,6 +1529,12 @@ __device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __r
   }
 }
 
+// Launch shape: ONE workgroup per CU, each bound to one branch for its whole life; a branch gets a share of the
+// workgroups proportional to its cost (host: ~3.1 k + 0.35 k cycles per K-32 slab and batch row) and a workgroup
+// a contiguous range of that branch's (tile, batch row) sequence.  The branch's weight fragments (75 KB for 7x7)
+// are DMA'd once per workgroup instead of once per 8 rows, and every CU finishes at about the same time; the
+// (tile, 8-row chunk, branch) grid of k_conv_bf runs 480 unequal workgroups (49 / 25 / 9 taps) on 256 CUs in
+// roughly 1.4 rounds - 92 us for 66 us of work (tools/stamps.py).
 template <int NS>
 __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -1536,19 +1543,44 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   const FtnDesc* __restrict__ d = a.desc;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int br = a.order[blockIdx.z];
+  int br = 0;
+  while (br + 1 < a.nbr && (int)blockIdx.x >= a.wg_off[br + 1]) ++br;
+  const int wgi = (int)blockIdx.x - a.wg_off[br], nwg = a.wg_off[br + 1] - a.wg_off[br];
+  const int G = d->n_groups, tiles_total = d->tiles_per_row;
+  const long long rows_total = (long long)tiles_total * a.B;
+  const int row_lo = (int)(rows_total * wgi / nwg), row_hi = (int)(rows_total * (wgi + 1) / nwg);
+  const size_t wgid = blockIdx.x;
+  stamp(a.dbg, a.dbg_cap, wgid, 0);
+  if (row_lo >= row_hi) return;
   const int kh = a.kh[br], kw = a.kw[br], hy = kh >> 1, hx = kw >> 1, ntaps = kh * kw;
   const int S = (ntaps + 1) >> 1;
+  if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) { a.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime(); a.dbg[wgid * 8 + 4] = (unsigned long long)ntaps; a.dbg[wgid * 8 + 5] = 0; }
   char* __restrict__ wl = ldsb;
-  char* __restrict__ rbuf0 = ldsb + a.wbytes;
+  char* __restrict__ rbuf0 = ldsb + (size_t)S * 3 * 1024;      // behind THIS branch's weight fragments
   const int zoff = plane - 64 + (qa & 1) * 16;               // zero pixel at the end of every plane
-  const int b_begin = blockIdx.y * a.bpw, b_end = min(a.B, b_begin + a.bpw);
-  const int G = d->n_groups, tiles_total = d->tiles_per_row;
-  if (threadIdx.x < 2 * NS * 4) {
+  if (threadIdx.x < 2 * NS * 4) {                            // zero pixels of both region buffers
     const int pl = threadIdx.x >> 2;
     *(f4*)(rbuf0 + (size_t)(pl / NS) * a.region_bytes + (size_t)(pl % NS) * plane + plane - 64 + (threadIdx.x & 3) * 16) = f4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int bx = blockIdx.x; bx < tiles_total; bx += gridDim.x) {
+  {                                                            // every slab of the branch's one output tile, once
+    const __bf16* __restrict__ src = a.W[br];
+    for (int f = wv; f < S * 3; f += 8)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(wl + (size_t)f * 1024), 16, 0, 0);
+  }
+  const f4 bv = *(const f4*)(a.bias + br * a.out_stride_br + 4 * qa);
+  const float inv = a.inv[br];
+  const int in_groups = a.INC >> 4;
+  const int btL = a.bt_L;
+  const int h1 = qa >> 1;                                     // this lane's tap of every pair
+  const unsigned kmh = (1u << kh) - 1u, kmw = (1u << kw) - 1u;
+  bool first_tile = true;
+
+  for (int row = row_lo; row < row_hi;) {
+    const int bx = row / a.B;                                  // tile (of the per-row tile list), then its batch rows
+    const int b_begin = row - bx * a.B;
+    const int b_end = min(a.B, b_begin + (row_hi - row));
+    row += b_end - b_begin;
     int g = 0;
     for (int gg = 1; gg < G; ++gg)
       if (bx >= d->g_tile_off[gg]) g = gg;
@@ -1563,11 +1595,9 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
     const int C0 = max(0, c0 - hx), C1 = min(p, c0 + tw + hx);
     const int RW = C1 - C0, RH = R1 - R0;
     const int npx = th * tw, nunits = (npx + 15) >> 4;
-    const int in_groups = a.INC >> 4;
     const float inv_tw = 1.0f / (float)tw, inv_rw = 1.0f / (float)RW;
     const int nchunks16 = RH * RW * 2;
     const int ppp = (nchunks16 + 63) >> 6;
-    const int btL = a.bt_L;
     auto dma_region = [&](int b, int buf) {
       const __bf16* __restrict__ src = a.in + (btL > 0 ? (size_t)b * btL : (size_t)a.B * d->g_px_off[g] + (size_t)b * P) * in_groups * PXE +
                                        (size_t)(br * a.in_stride_br) * PXE;
@@ -1579,16 +1609,23 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
         const int sp = ci >> 1, half = ci & 1;
         const int rr = (int)(((float)sp + 0.5f) * inv_rw), cx = sp - rr * RW;
         const int tpx = (R0 + rr) * p + C0 + cx;
-        const __bf16* __restrict__ row = (btL > 0 && tpx >= btL) ? src_pad : src + (size_t)tpx * in_groups * PXE;
+        const __bf16* __restrict__ rowp = (btL > 0 && tpx >= btL) ? src_pad : src + (size_t)tpx * in_groups * PXE;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(row + pz * 16 + half * 8),
+            (const __attribute__((address_space(1))) void*)(rowp + pz * 16 + half * 8),
             (__attribute__((address_space(3))) void*)(rbuf0 + (size_t)buf * a.region_bytes + (size_t)pz * plane + (size_t)pi * 1024), 16, 0, 0);
       }
     };
-    // per-lane pixel bookkeeping, once per tile
-    const int wrot = (wave + (int)blockIdx.y) & 7;
+    // the tile's first row is requested before the per-lane bookkeeping, so it lands meanwhile (the previous
+    // tile's readers must be done with the buffers first)
+    if (!first_tile) __syncthreads();
+    first_tile = false;
+    dma_region(b_begin, 0);
+    // per-lane pixel bookkeeping, once per tile.  Tap validity (conv zero padding at the grid border): bit s of
+    // vmask[u] = tap 2s + h1 lies inside the grid for this lane's pixel, from a row mask and a column mask and a
+    // division-free walk over the taps (a runtime tl / kw per slab and unit cost 20 k cycles of a 7x7 tile's
+    // 34 k cycle prologue, tools/stamps.py)
+    const int wrot = (wave + b_begin) & 7;
     const int nu = nunits > wrot ? (nunits - wrot + 7) >> 3 : 0;
-    const int h1 = qa >> 1;                                   // this lane's tap of every pair
     int ld[CBF_NU], oidx[CBF_NU];
     unsigned vmask[CBF_NU];
     bool pok[CBF_NU];
@@ -1601,34 +1638,30 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
       const int ri = r0 + r, ci = c0 + c;
       ld[u] = ((ri - R0 - hy) * RW + (ci - C0 - hx)) * CBF_PX_BYTES + (qa & 1) * 16 - zoff;
       oidx[u] = ri * p + ci;
+      // taps dy with 0 <= ri + dy - hy < cycles are the bits [lo, hi) of the row mask (same for columns)
+      const int rlo = max(0, hy - ri), rhi = min(kh, cycles + hy - ri);
+      const int clo = max(0, hx - ci), chi = min(kw, p + hx - ci);
+      const unsigned rm = (rhi > rlo) ? ((kmh >> (kh - rhi)) & (kmh << rlo)) & kmh : 0u;
+      const unsigned cm = (chi > clo) ? ((kmw >> (kw - chi)) & (kmw << clo)) & kmw : 0u;
       unsigned m = 0u;
-      if (pok[u]) {
-        for (int s = 0; s < S; ++s) {
-          const int tl = 2 * s + h1;
-          const int dy = tl / kw, dx = tl - dy * kw;
-          const int yy = ri + dy - hy, xx = ci + dx - hx;
-          if (tl < ntaps && yy >= 0 && yy < cycles && xx >= 0 && xx < p) m |= 1u << s;
-        }
+      int dy = 0, dx = h1;                                     // tap h1 of slab 0 (kw >= 3 > h1)
+      for (int s2 = 0; s2 < S; ++s2) {
+        const unsigned ok = (dy < kh) ? ((rm >> dy) & (cm >> dx) & 1u) : 0u;
+        m |= ok << s2;
+        dx += 2;
+        if (dx >= kw) { dx -= kw; ++dy; }
       }
-      vmask[u] = m;
+      vmask[u] = pok[u] ? m : 0u;
     }
-    __syncthreads();                                          // previous tile's readers are done
-    {                                                          // every slab of the branch's one output tile
-      const __bf16* __restrict__ src = a.W[br];
-      for (int f = wv; f < S * 3; f += 8)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 512 + lane * 8),
-                                         (__attribute__((address_space(3))) void*)(wl + (size_t)f * 1024), 16, 0, 0);
-    }
-    if (b_begin < b_end) dma_region(b_begin, 0);
     int it = 0;
-    const f4 bv = *(const f4*)(a.bias + br * a.out_stride_br + 4 * qa);
-    const float inv = a.inv[br];
     for (int b = b_begin; b < b_end; ++b) {
+      __syncthreads();                                        // row b (and, the first time, the weights) have landed
+      if (b == b_begin) stamp(a.dbg, a.dbg_cap, wgid, 1);
+      if (b == b_begin + 1) stamp(a.dbg, a.dbg_cap, wgid, 2);
+      if (b + 1 < b_end) dma_region(b + 1, (it + 1) & 1);
       f4 acc[CBF_NU];
 #pragma unroll
       for (int u = 0; u < CBF_NU; ++u) acc[u] = bv;
-      __syncthreads();                                        // region b and the weights have landed (vmcnt(0))
-      if (b + 1 < b_end) dma_region(b + 1, (it + 1) & 1);
       const char* __restrict__ reg = rbuf0 + (size_t)(it & 1) * a.region_bytes;
       ++it;
       const char* __restrict__ wlane = wl + lane * 16;
@@ -1647,6 +1680,8 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
       }
     }
   }
+  stamp(a.dbg, a.dbg_cap, wgid, 3);
+  if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) a.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---------------------------------------------------------------- small elementwise stages
@@ -2243,6 +2278,19 @@ static int launch_conv_bf_n(const ConvBfArgs& ca, const ConvBfGeom& gm, dim3 gri
   return launch_conv_bf_t<1, NS>(ca, grid, gm.lds, st);
 }
 
+static int launch_conv_bf_fast(const ConvBfArgs& ca, const ConvBfGeom& gm, dim3 grid, int nsplit, hipStream_t st) {
+  hipError_t e = hipSuccess;
+  if (nsplit == 3) e = hipFuncSetAttribute((const void*)k_conv_bf_fast<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
+  else if (nsplit == 2) e = hipFuncSetAttribute((const void*)k_conv_bf_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
+  else e = hipFuncSetAttribute((const void*)k_conv_bf_fast<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
+  if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_conv_bf_fast): %s", hipGetErrorString(e)); return (int)e; }
+  if (nsplit == 3) hipLaunchKernelGGL(k_conv_bf_fast<3>, grid, dim3(512), gm.lds, st, ca);
+  else if (nsplit == 2) hipLaunchKernelGGL(k_conv_bf_fast<2>, grid, dim3(512), gm.lds, st, ca);
+  else hipLaunchKernelGGL(k_conv_bf_fast<1>, grid, dim3(512), gm.lds, st, ca);
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
 static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_x, int nsplit, hipStream_t st) {
   const int nco_tot = ca.cout / 16;
   ca.nchunk = ftn_cdiv(nco_tot, gm.NCO);
@@ -2264,16 +2312,30 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
   }
   dim3 grid(grid_x, ftn_cdiv(B, ca.bpw), ca.nbr * ca.nchunk);
   if (gm.fast && ca.cin == 16 && ca.cout == 16) {
-    hipError_t e = hipSuccess;
-    if (nsplit == 3) e = hipFuncSetAttribute((const void*)k_conv_bf_fast<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
-    else if (nsplit == 2) e = hipFuncSetAttribute((const void*)k_conv_bf_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
-    else e = hipFuncSetAttribute((const void*)k_conv_bf_fast<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
-    if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_conv_bf_fast): %s", hipGetErrorString(e)); return (int)e; }
-    if (nsplit == 3) hipLaunchKernelGGL(k_conv_bf_fast<3>, grid, dim3(512), gm.lds, st, ca);
-    else if (nsplit == 2) hipLaunchKernelGGL(k_conv_bf_fast<2>, grid, dim3(512), gm.lds, st, ca);
-    else hipLaunchKernelGGL(k_conv_bf_fast<1>, grid, dim3(512), gm.lds, st, ca);
-    FTN_CHECK_LAUNCH();
-    return 0;
+    // one workgroup per CU, shared out over the branches in proportion to their cost per batch row
+    // (~3.1 k cycles + 0.35 k per K-32 slab, fitted to tools/stamps.py); every branch gets at least one
+    static int ncu = 0;
+    if (ncu == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+      if (ncu < ca.nbr) ncu = 256;
+    }
+    double cost[FTN_MAXBR], tot = 0.0;
+    size_t lds_fast = 0;
+    for (int k = 0; k < ca.nbr; ++k) {
+      const int S = (ca.kh[k] * ca.kw[k] + 1) / 2;
+      cost[k] = 3.1 + 0.345 * S; tot += cost[k];
+      const size_t need = (size_t)S * 3 * 1024 + 2 * (size_t)gm.region_bytes;
+      if (need > lds_fast) lds_fast = need;
+    }
+    int used = 0, nwg[FTN_MAXBR];
+    for (int k = 0; k < ca.nbr; ++k) { nwg[k] = (int)(ncu * cost[k] / tot); if (nwg[k] < 1) nwg[k] = 1; used += nwg[k]; }
+    for (int k = 0; used < ncu; k = (k + 1) % ca.nbr) { ++nwg[k]; ++used; }     // leftovers round-robin from the first branch
+    for (int k = 0; used > ncu && k < ca.nbr; ++k) while (nwg[k] > 1 && used > ncu) { --nwg[k]; --used; }
+    ca.wg_off[0] = 0;
+    for (int k = 0; k < ca.nbr; ++k) ca.wg_off[k + 1] = ca.wg_off[k] + nwg[k];
+    const ConvBfGeom gmf = {gm.NCO, lds_fast, gm.plane_bytes, gm.region_bytes, gm.wbytes, gm.sgroup, true};
+    return launch_conv_bf_fast(ca, gmf, dim3((unsigned)ca.wg_off[ca.nbr]), nsplit, st);
   }
   if (nsplit == 3) return launch_conv_bf_n<3>(ca, gm, grid, st);
   if (nsplit == 2) return launch_conv_bf_n<2>(ca, gm, grid, st);
