@@ -37,6 +37,8 @@ static unsigned long long* g_stamp_buf = nullptr;
 static size_t g_stamp_cap = 0;
 static int g_stamp_which = 0;  // 1: k_conv, 2: k_mlp
 static const bool g_conv_generic = [] { const char* e = getenv("FTN_CONV_GENERIC"); return e != nullptr && e[0] == '1'; }();  // experiment switch
+static const bool g_mlp_w16 = [] { const char* e = getenv("FTN_MLP_W16"); return e != nullptr && e[0] == '1'; }();   // experiment: 16-wave double-buffered k_mlp_bf_u1
+static const bool g_mlp_w4 = [] { const char* e = getenv("FTN_MLP_W4"); return e != nullptr && e[0] == '1'; }();     // experiment: 4-wave workgroups, three per CU
 static const bool g_mlp_u1 = [] { const char* e = getenv("FTN_MLP_U1"); return e == nullptr || e[0] != '0'; }();    // 0: the two-unit k_mlp_bf
 __device__ __forceinline__ void stamp(unsigned long long* buf, size_t cap, size_t wg, int slot) {
   if (buf != nullptr && threadIdx.x == 0 && (wg * 8 + slot) < cap) buf[wg * 8 + slot] = __builtin_amdgcn_s_memtime();
@@ -805,23 +807,31 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
 // SKM / SCP = K=32 slabs of layer 1 / of the residual, OTM = output tiles: <3, 4, 14> is that shape; <2, 2, 7> is
 // d_model 64 with three kernels of mid 16 (48 -> 64 K padding), where the smaller register footprint lets two
 // 8-wave workgroups = four waves per SIMD share a CU (the two-unit k_mlp_bf above runs two).
-template <int ACT, bool XVEC, int NS, int SKM, int SCP, int OTM>
-__global__ __launch_bounds__(512, 2) void k_mlp_bf_u1(MlpBfArgs a) {
+// NWV = 16 (one 256-pixel workgroup per CU, chunk weights DOUBLE-buffered): every hidden chunk's 45 KB of
+// weight fragments is streamed L2 -> LDS once per workgroup, i.e. 360 KB per pixel tile: with 128-pixel tiles that
+// is 1.2 GB per launch at the bench shape, and the LDS-DMA fill rate (~25 GB/s per CU, 6.4 TB/s per chip,
+// MI355X_MICROARCH.md 'ldsdma-fill') makes that stream alone ~190 us of a 250 us launch.  256-pixel tiles halve
+// it, and with only one workgroup per CU the second buffer fits, so chunk c+1 lands while chunk c is computed
+// (one barrier per chunk instead of two around an exposed refill).  NWV = 8: two single-buffered workgroups per CU.
+template <int ACT, bool XVEC, int NS, int SKM, int SCP, int OTM, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void k_mlp_bf_u1(MlpBfArgs a) {
   constexpr int NFR = 2 * SKM + 2 * SCP + OTM;
+  constexpr int NBUF = NWV == 16 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char wlb[];
   const FtnDesc* __restrict__ d = a.desc;
   const int N = a.B * d->total_px;
-  if ((int)(blockIdx.x * 8 * 16) >= N) return;
+  if ((int)(blockIdx.x * NWV * 16) >= N) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int n0 = (blockIdx.x * 8 + wave) * 16;
+  const int n0 = (blockIdx.x * NWV + wave) * 16;
   const bool active = n0 < N;
   const int bufsz = NFR * 3 * 1024;
   auto dma_chunk = [&](int hc) {
     const __bf16* __restrict__ src = a.cfrag + (size_t)hc * NFR * 3 * 512;
-    for (int piece = wv; piece < NFR * 3; piece += 8)
+    char* dst = wlb + (size_t)(NBUF == 2 ? (hc & 1) : 0) * bufsz;
+    for (int piece = wv; piece < NFR * 3; piece += NWV)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
-                                       (__attribute__((address_space(3))) void*)(wlb + (size_t)piece * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + (size_t)piece * 1024), 16, 0, 0);
   };
   const Px px = decode_px(d, a.x, a.B, a.L, a.C, n0 + j, N);
   const int CP = a.CP;
@@ -845,8 +855,8 @@ __global__ __launch_bounds__(512, 2) void k_mlp_bf_u1(MlpBfArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   dma_chunk(0);
   const int FPc = a.n_hchunks * 32;
-  float* __restrict__ bias_l = (float*)(wlb + (size_t)bufsz);
-  for (int i = threadIdx.x; i < 2 * FPc; i += 512) {
+  float* __restrict__ bias_l = (float*)(wlb + (size_t)NBUF * bufsz);
+  for (int i = threadIdx.x; i < 2 * FPc; i += NWV * 64) {
     const int c = i < FPc ? i : i - FPc;
     bias_l[i] = c < a.FP ? (i < FPc ? a.bo[c] : a.br[c]) : 0.f;
   }
@@ -871,7 +881,9 @@ __global__ __launch_bounds__(512, 2) void k_mlp_bf_u1(MlpBfArgs a) {
   for (int o = 0; o < OTM; ++o) oacc[o] = *(const f4*)(a.bc + 16 * o + 4 * qa);
   __syncthreads();
   for (int hc = 0; hc < a.n_hchunks; ++hc) {
-    const char* __restrict__ wl = wlb + lane * 16;
+    const char* __restrict__ wl = wlb + (size_t)(NBUF == 2 ? (hc & 1) : 0) * bufsz + lane * 16;
+    // double-buffered: the other buffer was last read in chunk hc - 1, which every wave left at the barrier
+    if (NBUF == 2 && hc + 1 < a.n_hchunks) dma_chunk(hc + 1);
     f4 bo_t[2], br_t[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -912,7 +924,7 @@ __global__ __launch_bounds__(512, 2) void k_mlp_bf_u1(MlpBfArgs a) {
       }
     }
     __syncthreads();
-    if (hc + 1 < a.n_hchunks) {
+    if (NBUF == 1 && hc + 1 < a.n_hchunks) {
       dma_chunk(hc + 1);
       __syncthreads();
     }
@@ -930,18 +942,29 @@ __global__ __launch_bounds__(512, 2) void k_mlp_bf_u1(MlpBfArgs a) {
   }
 }
 
-template <int ACT, int NS, int SKM, int SCP, int OTM>
-static int launch_mlp_bf_u1(MlpBfArgs ma, bool xvec, long long Nmax, hipStream_t st) {
+template <int ACT, int NS, int SKM, int SCP, int OTM, int NWV>
+static int launch_mlp_bf_u1w(MlpBfArgs ma, bool xvec, long long Nmax, hipStream_t st) {
   ma.dbg = nullptr; ma.dbg_cap = 0;
-  const size_t lds = (size_t)ma.per_chunk * 3 * 1024 + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
-  const int nblk = (int)((Nmax + 127) / 128);
-  hipError_t e = xvec ? hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                      : hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = (size_t)ma.per_chunk * 3 * 1024 * (NWV == 16 ? 2 : 1) + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
+  if (lds > 160 * 1024) { ftn_set_error("stage C needs %zu B of LDS", lds); return -1; }
+  const int nblk = (int)((Nmax + NWV * 16 - 1) / (NWV * 16));
+  hipError_t e = xvec ? hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                      : hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_bf_u1): %s", hipGetErrorString(e)); return (int)e; }
-  if (xvec) hipLaunchKernelGGL((k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM>), dim3(nblk), dim3(512), lds, st, ma);
-  else hipLaunchKernelGGL((k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM>), dim3(nblk), dim3(512), lds, st, ma);
+  if (xvec) hipLaunchKernelGGL((k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
+  else hipLaunchKernelGGL((k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
   FTN_CHECK_LAUNCH();
   return 0;
+}
+
+template <int ACT, int NS, int SKM, int SCP, int OTM>
+static int launch_mlp_bf_u1(const MlpBfArgs& ma, bool xvec, long long Nmax, hipStream_t st) {
+  // 16-wave double-buffered form where two chunk buffers fit LDS (d_model 64: 2 x 45 KB) unless FTN_MLP_W16=0
+  if (g_mlp_w16 && (size_t)ma.per_chunk * 3 * 1024 * 2 + (size_t)ma.n_hchunks * 256 <= 160 * 1024)
+    return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 16>(ma, xvec, Nmax, st);
+  if (g_mlp_w4 && ((size_t)ma.per_chunk * 3 * 1024 + (size_t)ma.n_hchunks * 256) * 3 <= 160 * 1024)
+    return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 4>(ma, xvec, Nmax, st);
+  return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 8>(ma, xvec, Nmax, st);
 }
 
 template <int ACT, int NS>
