@@ -50,6 +50,9 @@ class GraphedForward:
             if self._has_checks:
                 module._defer_checks = False
         self._pending = getattr(module, "_pending_bad", None)
+        # the captured launches have the packed weight blobs' addresses baked in: keep them alive even if a block
+        # repacks later (new weights need a new capture)
+        self._packs = [m._pack for m in module.modules() if getattr(m, "_pack", None) is not None]
 
     @staticmethod
     def _refill(dst: Any, src: Any) -> None:

@@ -361,6 +361,15 @@ class TimesBlock(nn.Module):
             self._pack_key = key
         return self._pack
 
+    def invalidate_pack(self) -> None:
+        """Forget the packed weight blob.  The cache is keyed on the parameters' storage pointers and version
+        counters, which catches ``load_state_dict`` / optimiser steps / ``.to()``; inference tensors carry no
+        version counter, so after an IN-PLACE update of parameters created under ``torch.inference_mode`` call
+        this (or replace the parameters) before the next forward.  Graphs captured earlier keep the blob they
+        were captured with (``graph.GraphedForward`` holds a reference)."""
+        self._pack_key = None
+        self._pack = None
+
     # ---- forward ---------------------------------------------------------------
     def forward(self, x: torch.Tensor, post_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
         """``post_norm`` (extension, used by the TimesNet shell in eval mode): also apply the model's
