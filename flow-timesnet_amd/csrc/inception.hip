@@ -127,16 +127,16 @@ __device__ __forceinline__ f4 load_x4(const float* __restrict__ xrow, int c, int
 // Stage A always runs here; EPI 4-6 with XIN 0 / 2 form the generic stage C for widths beyond the fused
 // kernels' limits (more than 16 output tiles, or a hidden chunk's fragments not fitting LDS twice).
 template <int ACT, int XIN, bool XVEC, int EPI>
-__global__ __launch_bounds__(256) void k_pw(PwArgs a) {
+__device__ __forceinline__ void pw_body(const PwArgs& a, const int bid) {
   // XIN 1 (stage A): a = W_in1 x + b depends on (b, t) only, not on the period group, so it is computed once per
   // window position - rows n = b*L + t of `out` - plus ONE pad row n = B*L for the live zero pixels t >= L of
   // every grid (x = 0 there, :1017, so a = bias).  The conv stage folds these rows into its period grids while
   // staging (ConvArgs.bt_L), which is the reference's reshape (:1041-1046) done by index arithmetic.
   const FtnDesc* __restrict__ d = a.desc;
-  if (XIN == 1 && blockIdx.x == 0 && a.guard_dst != nullptr) guard_desc(a.guard_src, a.guard_dst, a.guard_groups, a.guard_px);
+  if (XIN == 1 && bid == 0 && a.guard_dst != nullptr) guard_desc(a.guard_src, a.guard_dst, a.guard_groups, a.guard_px);
   const int N = XIN == 1 ? a.B * a.L + 1 : a.B * d->total_px;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-  const int n0 = (blockIdx.x * 4 + wave) * (16 * NPXU);
+  const int n0 = (bid * 4 + wave) * (16 * NPXU);
   if (n0 >= N) return;
   Px px[NPXU];
 #pragma unroll
@@ -201,6 +201,27 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) {
         }
       }
     }
+  }
+}
+
+template <int ACT, int XIN, bool XVEC, int EPI>
+__global__ __launch_bounds__(256) void k_pw(PwArgs a) { pw_body<ACT, XIN, XVEC, EPI>(a, (int)blockIdx.x); }
+
+// Stage A has no use for the selector's result, and the selector ends in a one-workgroup kernel (k_finalize, ~17 us
+// of serial latency with 255 CUs idle): this launch runs both - workgroup 0 is k_finalize (and then publishes the
+// sanitised descriptor copy at the head of the workspace), workgroups 1.. are stage A - so stage A's ~22 us
+// disappear behind the selector's tail (ftn_period_finalize_stage_a).
+#include "ftn_finalize.h"
+template <int ACT, bool XVEC, int EPI>
+__global__ __launch_bounds__(256) void k_finalize_pw(FinalizeArgs fa, PwArgs pa) {
+  if (blockIdx.x == 0) {
+    finalize_body(fa);
+    __syncthreads();
+    guard_desc(fa.desc, pa.guard_dst, pa.guard_groups, pa.guard_px);
+  } else {
+    PwArgs q = pa;
+    q.guard_dst = nullptr;
+    pw_body<ACT, 1, XVEC, EPI>(q, (int)blockIdx.x - 1);
   }
 }
 
@@ -2441,7 +2462,7 @@ static int launch_mlp_bf(const MlpBfArgs& ma, bool xvec, long long Nmax, hipStre
 template <int ACT>
 static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, const float* wb, const FtnDesc* desc_in,
                      const float* wts, int max_groups, int px_bound, char* ws, hipStream_t st, const float* ln_g,
-                     const float* ln_b, float ln_eps, int act_dtype) {
+                     const float* ln_b, float ln_eps, int act_dtype, int flags) {
   const WsLayout wl = ws_layout(pl, B, L, max_groups, px_bound);
   const int px_row = worst_px_per_row(L, max_groups, px_bound);
   const FtnDesc* desc = (const FtnDesc*)ws;     // sanitised copy, written by the first launch (stage A)
@@ -2476,7 +2497,8 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = bufA; pa.desc = desc;
     pa.B = B; pa.L = L; pa.C = C; pa.KIN = CP; pa.n_ot = CA / 16; pa.OUTC = CA;
     pa.guard_src = desc_in; pa.guard_dst = (FtnDesc*)ws; pa.guard_groups = max_groups; pa.guard_px = px_row;
-    if (use_bf && h2) { if ((rc = launch_pw<ACT, 1, 3>(pa, xvec, nblk_pw, st))) return rc; }
+    if (flags & FTN_FWD_STAGE_A_DONE) { /* ftn_period_finalize_stage_a ran stage A and published the descriptor copy */ }
+    else if (use_bf && h2) { if ((rc = launch_pw<ACT, 1, 3>(pa, xvec, nblk_pw, st))) return rc; }
     else if (use_bf) { if ((rc = launch_pw<ACT, 1, 2>(pa, xvec, nblk_pw, st))) return rc; }
     else if ((rc = launch_pw<ACT, 1, 0>(pa, xvec, nblk_pw, st))) return rc;
     prof_mark(1, st);
@@ -2649,7 +2671,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
 static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev, int max_groups,
                            int px_bound, void* ws_dev, size_t ws_bytes, void* stream, const float* ln_g, const float* ln_b,
-                           float ln_eps, int act_dtype) {
+                           float ln_eps, int act_dtype, int flags) {
   FTN_CHECK_ARG(x_dev && y_dev && plan && wblob_dev && desc_dev && weights_dev && ws_dev,
                 "ftn_timesblock_forward: null pointer");
   FTN_CHECK_ARG(B >= 1 && B <= 65535 && L >= 2, "ftn_timesblock_forward: bad shape B=%d L=%d", B, L);
@@ -2661,6 +2683,8 @@ static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const
   FTN_CHECK_ARG(plan->res1 || plan->CP == plan->FP, "identity res1 needs d_model == d_ff");
   FTN_CHECK_ARG(plan->res2 || plan->CP == plan->FP, "identity res2 needs d_model == d_ff");
   FTN_CHECK_ARG(px_bound >= 0, "ftn_timesblock_forward: px_bound=%d", px_bound);
+  FTN_CHECK_ARG((flags & ~FTN_FWD_STAGE_A_DONE) == 0 && !((flags & FTN_FWD_STAGE_A_DONE) && plan->mode != 0),
+                "ftn_timesblock_forward: flags=%d", flags);
   FTN_CHECK_ARG(act_dtype >= 0 && act_dtype <= 2 && !(act_dtype != 0 && ln_g != nullptr),
                 "ftn_timesblock_forward: act_dtype=%d (the fused LayerNorm epilogue is fp32 only)", act_dtype);
   const size_t need = ftn_timesblock_workspace_bytes(plan, B, L, max_groups, px_bound);
@@ -2670,27 +2694,87 @@ static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const
                 "ftn_timesblock_forward: workspace/weights must be 256/16-byte aligned");
   if (plan->act == 1)
     return forward_t<1>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, (char*)ws_dev,
-                        (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype);
+                        (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype, flags);
   return forward_t<0>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, (char*)ws_dev,
-                      (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype);
+                      (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype, flags);
+}
+
+// S3-S5 of the selector and stage A of the block in ONE launch (k_finalize_pw): see flowtimes.h
+template <int ACT>
+static int finalize_stage_a_t(const FinalizeArgs& fa, const PwArgs& pa, int epi, bool xvec, int nblk_pw, size_t lds,
+                              hipStream_t st) {
+  const dim3 grid(1 + nblk_pw), blk(256);
+  if (xvec) {
+    if (epi == 3) hipLaunchKernelGGL((k_finalize_pw<ACT, true, 3>), grid, blk, lds, st, fa, pa);
+    else if (epi == 2) hipLaunchKernelGGL((k_finalize_pw<ACT, true, 2>), grid, blk, lds, st, fa, pa);
+    else hipLaunchKernelGGL((k_finalize_pw<ACT, true, 0>), grid, blk, lds, st, fa, pa);
+  } else {
+    if (epi == 3) hipLaunchKernelGGL((k_finalize_pw<ACT, false, 3>), grid, blk, lds, st, fa, pa);
+    else if (epi == 2) hipLaunchKernelGGL((k_finalize_pw<ACT, false, 2>), grid, blk, lds, st, fa, pa);
+    else hipLaunchKernelGGL((k_finalize_pw<ACT, false, 0>), grid, blk, lds, st, fa, pa);
+  }
+  FTN_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B,
+                                           int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
+                                           int max_unique, float log_base, FtnDesc* desc_dev, float* amps_dev,
+                                           float* weights_dev, const float* x_dev, const FtnPlan* plan,
+                                           const float* wblob_dev, int max_groups, int px_bound, void* ws_dev,
+                                           size_t ws_bytes, void* stream) {
+  FTN_CHECK_ARG(psum_dev && med_dev && desc_dev && amps_dev && weights_dev && x_dev && plan && wblob_dev && ws_dev,
+                "ftn_period_finalize_stage_a: null pointer");
+  FTN_CHECK_ARG(B >= 1 && B <= 65535 && L >= 2 && nparts >= 1 && Btotal >= B, "ftn_period_finalize_stage_a: bad shape");
+  FTN_CHECK_ARG(k_periods <= FTN_KMAX && act_dtype >= 0 && act_dtype <= 2, "ftn_period_finalize_stage_a: k=%d act_dtype=%d", k_periods, act_dtype);
+  FTN_CHECK_ARG(plan->mode == 0 && plan->MP > 0 && plan->MP % 16 == 0, "ftn_period_finalize_stage_a: bottleneck blocks only");
+  FTN_CHECK_ARG(max_groups >= 1 && max_groups <= FTN_KMAX && px_bound >= 0, "ftn_period_finalize_stage_a: bounds");
+  const size_t need = ftn_timesblock_workspace_bytes(plan, B, L, max_groups, px_bound);
+  FTN_CHECK_ARG(need > 0 && ws_bytes >= need && ((uintptr_t)ws_dev & 255) == 0 && ((uintptr_t)wblob_dev & 15) == 0,
+                "ftn_period_finalize_stage_a: workspace %zu < %zu bytes or misaligned", ws_bytes, need);
+  if (k_periods < 0) k_periods = 0;
+  if (pmax < 1) pmax = 1;
+  if (min_period_threshold < 1) min_period_threshold = 1;
+  if (min_period_threshold > pmax) min_period_threshold = pmax;
+  const int F = L / 2 + 1;
+  const size_t lds = (size_t)F * sizeof(float);
+  FTN_CHECK_ARG(lds <= 48 * 1024, "ftn_period_finalize_stage_a: L=%d too long", L);
+  const WsLayout wl = ws_layout(plan, B, L, max_groups, px_bound);
+  const int CA = plan->nbr * plan->MP;
+  const int nsplit = plan->engine == 2 ? 1 : (plan->engine == 3 ? 2 : 3);
+  ConvBfGeom bfg = {0, 0, 0, 0, 0, 0};
+  if (plan->engine != 0) bfg = conv_bf_geom(L, plan->nbr, plan->kh, plan->kw, plan->MP, nsplit);
+  const bool use_bf = plan->engine != 0 && bfg.NCO > 0;
+  const int epi = !use_bf ? 0 : (plan->engine == 3 ? 3 : 2);
+  FinalizeArgs fa = {psum_dev, nparts, Btotal, med_dev, B, L, F, k_periods, pmax, min_period_threshold, desc_dev,
+                     amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0f ? log_base : 0.f};
+  PwArgs pa = {};
+  pa.x = x_dev; pa.W = wblob_dev + plan->w_in1; pa.bias = wblob_dev + plan->b_in1; pa.out = (float*)((char*)ws_dev + wl.offA);
+  pa.desc = nullptr; pa.B = B; pa.L = L; pa.C = plan->C; pa.KIN = plan->CP; pa.n_ot = CA / 16; pa.OUTC = CA;
+  pa.guard_src = desc_dev; pa.guard_dst = (FtnDesc*)ws_dev; pa.guard_groups = max_groups;
+  pa.guard_px = worst_px_per_row(L, max_groups, px_bound);
+  const bool xvec = (plan->C % 4 == 0) && (((uintptr_t)x_dev & 15) == 0);
+  const int nblk_pw = (int)(((long long)B * L + 1 + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));
+  if (plan->act == 1) return finalize_stage_a_t<1>(fa, pa, epi, xvec, nblk_pw, lds, (hipStream_t)stream);
+  return finalize_stage_a_t<0>(fa, pa, epi, xvec, nblk_pw, lds, (hipStream_t)stream);
 }
 
 extern "C" int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                       const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                                      int max_groups, int px_bound, int act_dtype, void* ws_dev, size_t ws_bytes,
-                                      void* stream) {
+                                      int max_groups, int px_bound, int act_dtype, int flags, void* ws_dev,
+                                      size_t ws_bytes, void* stream) {
   return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, ws_dev, ws_bytes,
-                         stream, nullptr, nullptr, 0.f, act_dtype);
+                         stream, nullptr, nullptr, 0.f, act_dtype, flags);
 }
 
 extern "C" int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                                           int max_groups, int px_bound, const float* ln_gamma_dev,
+                                           int max_groups, int px_bound, int flags, const float* ln_gamma_dev,
                                            const float* ln_beta_dev, float ln_eps, void* ws_dev, size_t ws_bytes,
                                            void* stream) {
   FTN_CHECK_ARG(ln_gamma_dev && ln_beta_dev && ln_eps >= 0.f, "ftn_timesblock_forward_norm: LayerNorm parameters");
   return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, ws_dev,
-                         ws_bytes, stream, ln_gamma_dev, ln_beta_dev, ln_eps, 0);
+                         ws_bytes, stream, ln_gamma_dev, ln_beta_dev, ln_eps, 0, flags);
 }
 
 extern "C" int ftn_residual_layernorm(const float* x_dev, const float* new_dev, float* out_dev, long long rows, int C,

@@ -336,363 +336,9 @@ extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, cons
 }
 
 // ---------------------------------------------------------------- S3 - S5
-struct ArgMax { float v; int i; };
+#include "ftn_finalize.h"
 
-// Half-precision inputs (act_dtype 1 = bf16, 2 = fp16): the reference rounds the batch-mean spectrum, the
-// scores, the returned amplitudes, the softmax weights and their per-group sums to the input dtype
-// (:124, :130, :159, :1000, :1009 scatter_add_ in that dtype); rnd() is that rounding, the identity for fp32.
-__device__ __forceinline__ float rnd_act(float v, int act_dtype) {
-  if (act_dtype == 1) return (float)(__bf16)v;
-  if (act_dtype == 2) return (float)(_Float16)v;
-  return v;
-}
-
-__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
-  // larger value wins; ties -> lower index (torch.topk's tie order is
-  // implementation-defined; we fix lowest-index-first)
-  if (b.i >= 0 && (a.i < 0 || b.v > a.v || (b.v == a.v && b.i < a.i))) return b;
-  return a;
-}
-
-__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ psum, int nparts, int Btotal,
-                                                  const float* __restrict__ med, int B, int L, int F, int kcfg,
-                                                  int pmax, int min_thr, FtnDesc* __restrict__ desc,
-                                                  float* __restrict__ amps, float* __restrict__ wts, int act_dtype,
-                                                  int max_unique, float log_base) {
-  extern __shared__ __attribute__((aligned(16))) float score[];  // [F]
-  __shared__ int sel_idx[FTN_KMAX];
-  __shared__ FtnDesc sd;
-  __shared__ float red[256][FTN_KMAX + 1];                        // block reductions of the flagged grouping
-  __shared__ float colmean[FTN_KMAX], gscore[FTN_KMAX];
-  __shared__ int c_assign[FTN_KMAX];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  // mean over the (global) batch, DC kill, log penalty          (:112-130)
-  for (int f = tid; f < F; f += 256) {
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += psum[(size_t)p * F + f];
-    float m = rnd_act((float)(s / (double)Btotal), act_dtype);
-    float sc = rnd_act(m - rnd_act(1e-8f * rnd_act(log1pf((float)f), act_dtype), act_dtype), act_dtype);
-    score[f] = (f == 0) ? -INFINITY : sc;
-  }
-  __syncthreads();
-  int k = kcfg < F - 1 ? kcfg : F - 1;                            // :122-123
-  if (k > FTN_KMAX) k = FTN_KMAX;
-  if (k < 0) k = 0;
-  // top-k by ONE wavefront, no barriers: every lane keeps the best of its strided share of the bins, a
-  // shuffle butterfly reduces the 64 candidates, the winner's bin is retired (NaN) and the lane that owned it
-  // rescans its share.  k <= 16 rounds of ~12 shuffles; ties resolve to the lowest bin index.
-  if (wave == 0) {
-    ArgMax mine = {0.f, -1};
-    for (int f = lane; f < F; f += 64) {
-      const float v = score[f];
-      if (v == v) mine = better(mine, ArgMax{v, f});
-    }
-    for (int r = 0; r < k; ++r) {
-      ArgMax best = mine;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        ArgMax o;
-        o.v = __shfl_xor(best.v, off);
-        o.i = __shfl_xor(best.i, off);
-        best = better(best, o);
-      }
-      if (lane == 0) sel_idx[r] = best.i;
-      if (best.i >= 0 && (best.i & 63) == lane) {          // owner: retire the bin, rescan its share
-        score[best.i] = __builtin_nanf("");
-        mine = ArgMax{0.f, -1};
-        for (int f = lane; f < F; f += 64) {
-          const float v = score[f];
-          if (v == v) mine = better(mine, ArgMax{v, f});
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // periods, validity, grouping and tiling by the lanes of wave 0 in parallel - lane j owns candidate j, then
-  // group j (FTN_KMAX <= 64).  Integer division has no hardware instruction here (~40 VALU ops each), and the
-  // ~100 divisions of this section (period = ceil(L/idx), pad, cycles, the tile-geometry search) used to run one
-  // after another on a single lane: 13 us of a 24 us kernel.  Same results as ftn_build_groups (host).
-  if (wave == 0) {
-    const int hi = pmax < (L - 1 > 1 ? L - 1 : 1) ? pmax : (L - 1 > 1 ? L - 1 : 1);   // :138
-    const int lo = min_thr;                                                            // :139
-    // -- candidate j: period, kept by the selector? (:144-148)
-    int idx = (lane < k) ? sel_idx[lane] : -1;
-    bool kept = false;
-    int p = 0;
-    if (idx >= 0 && hi >= lo) {
-      if (idx < 1) idx = 1;                                       // clamp_min(1) :132
-      p = (L + idx - 1) / idx;                                    // :144
-      p = p < lo ? lo : (p > hi ? hi : p);                        // :145
-      kept = (L + p - 1) / p >= 2;                                // :147-148
-    }
-    const unsigned long long keptm = __ballot(kept);
-    const int nsel = __popcll(keptm);
-    const int slot = __popcll(keptm & ((1ull << lane) - 1ull));   // position among the kept candidates (score order)
-    if (lane < FTN_KMAX) { sd.sel_freq[lane] = 0; sd.sel_period[lane] = 0; sd.sel_group[lane] = -1; }
-    if (kept) { sd.sel_freq[slot] = idx; sd.sel_period[slot] = p; }
-    // -- grouping (PeriodGrouper.group, flags unset, :513-557): lane s < nsel now owns kept candidate s
-    // period of kept candidate `lane`: gather from its owner = the lane holding the (lane+1)-th set bit of keptm
-    int owner = 0;
-    {
-      unsigned long long m = keptm;
-      for (int t = 0; t < FTN_KMAX; ++t) {                        // t-th set bit -> lane t
-        const int bit = m ? __ffsll((unsigned long long)m) - 1 : 0;
-        if (t == lane) owner = bit;
-        m &= m - 1ull;
-      }
-    }
-    const int pc = __shfl(p, owner);                              // period of kept candidate `lane` (lane < nsel)
-    // grouper filter: p > 0, lo <= p <= pmax, cycles >= 2 (:517-543)
-    int pad = 0, cyc = 0;
-    bool valid = false;
-    if (lane < nsel && pc > 0 && pc >= lo && pc <= pmax) {
-      pad = (pc - (L % pc)) % pc;
-      cyc = (L + pad) / pc;
-      valid = cyc >= 2;
-    }
-    // distinct valid periods, ascending: first = no earlier candidate with the same period;
-    // rank = number of distinct valid periods below mine
-    bool first = valid;
-    int rank = 0;
-    for (int t = 0; t < FTN_KMAX; ++t) {
-      const int pt = __shfl(pc, t);
-      const bool vt = __shfl((int)valid, t) != 0;
-      if (vt && pt == pc && t < lane) first = false;
-    }
-    for (int t = 0; t < FTN_KMAX; ++t) {
-      const int pt = __shfl(pc, t);
-      const bool ft = __shfl((int)first, t) != 0;
-      if (ft && pt < pc) ++rank;
-    }
-    const int G = __popcll(__ballot(first));
-    if (valid) sd.sel_group[lane] = rank;
-    int tw = 0, th = 0, ntx = 0, nty = 0;
-    if (first) ftn_tile_geometry(cyc, pc, &tw, &th, &ntx, &nty);
-    if (lane < FTN_KMAX) {                                        // defaults for the unused group slots
-      sd.g_period[lane] = 0; sd.g_pad[lane] = 0; sd.g_cycles[lane] = 0;
-      sd.g_tw[lane] = 0; sd.g_th[lane] = 0; sd.g_ntx[lane] = 0; sd.g_nty[lane] = 0;
-    }
-    if (first) {
-      sd.g_period[rank] = pc; sd.g_pad[rank] = pad; sd.g_cycles[rank] = cyc;
-      sd.g_tw[rank] = tw; sd.g_th[rank] = th; sd.g_ntx[rank] = ntx; sd.g_nty[rank] = nty;
-    }
-    // prefix sums over the groups in ascending order: lane g re-reads group g (same wave: LDS ops are in order)
-    const int gpx = (lane < G) ? L + sd.g_pad[lane] : 0;
-    const int gtl = (lane < G) ? sd.g_ntx[lane] * sd.g_nty[lane] : 0;
-    int opx = 0, otl = 0;                                         // exclusive prefix of lanes < lane
-    for (int t = 0; t < FTN_KMAX; ++t) {
-      const int a_ = __shfl(gpx, t), b_ = __shfl(gtl, t);
-      if (t < lane) { opx += a_; otl += b_; }
-    }
-    if (lane <= FTN_KMAX) { sd.g_px_off[lane] = opx; sd.g_tile_off[lane] = otl; }   // lanes >= G hold the totals
-    if (lane == 0) {
-      sd.n_sel = nsel; sd.n_groups = G;
-    }
-    if (lane == FTN_KMAX) { sd.total_px = opx; sd.tiles_per_row = otl; }
-  }
-  __syncthreads();
-  // ---- TIMES_PERIOD_BINNING / TIMES_PERIOD_MAX_UNIQ (reference :350-437; resolved per block depth on the host and
-  //      passed in): candidates are grouped by log bucket instead of by period, and / or only the `max_unique`
-  //      groups with the largest batch-mean logsumexp survive, the others joining the kept group of nearest
-  //      period.  A group's period is its member with the largest batch-mean amplitude.  Needs two reductions
-  //      over the batch (column means, group scores), done in a fixed order; the small-K logic runs on thread 0.
-  if (max_unique > 0 || log_base > 1.0f) {
-    const int nsel = sd.n_sel;
-    float part[FTN_KMAX];
-#pragma unroll
-    for (int j = 0; j < FTN_KMAX; ++j) part[j] = 0.f;
-    for (int b = tid; b < B; b += 256)
-#pragma unroll
-      for (int j = 0; j < FTN_KMAX; ++j)
-        if (j < nsel) part[j] += rnd_act(med[(size_t)b * F + sd.sel_freq[j]], act_dtype);
-#pragma unroll
-    for (int j = 0; j < FTN_KMAX; ++j) red[tid][j] = part[j];
-    __syncthreads();
-    if (tid < FTN_KMAX) {
-      float t = 0.f;
-      for (int r = 0; r < 256; ++r) t += red[r][tid];
-      colmean[tid] = rnd_act(t / (float)B, act_dtype);
-    }
-    __syncthreads();
-    // validity of every kept candidate under the grouper's filter (:517-543), initial assignment by key (:547-551)
-    if (tid == 0) {
-      int key[FTN_KMAX];
-      for (int j = 0; j < FTN_KMAX; ++j) c_assign[j] = -1;
-      for (int j = 0; j < nsel; ++j) {
-        const int p = sd.sel_period[j];
-        bool ok = p > 0 && p >= min_thr && p <= pmax;
-        if (ok) { const int pad = (p - (L % p)) % p; ok = (L + pad) / p >= 2; }
-        key[j] = !ok ? -1 : (log_base > 1.0f ? (int)floorf(logf((float)p) / logf(log_base) + 1e-6f) : p);   // :350-354
-        if (!ok) continue;
-        // assignment id = rank of the key among the distinct keys (sorted ascending), filled below
-      }
-      for (int j = 0; j < nsel; ++j) {
-        if (key[j] < 0) continue;
-        int rank = 0;
-        for (int i = 0; i < nsel; ++i) {
-          if (key[i] < 0 || key[i] >= key[j]) continue;
-          bool firstocc = true;
-          for (int h = 0; h < i; ++h) if (key[h] == key[i]) firstocc = false;
-          if (firstocc) ++rank;
-        }
-        c_assign[j] = rank;
-      }
-    }
-    __syncthreads();
-    int ngroups = 0;
-    for (int j = 0; j < nsel; ++j) if (c_assign[j] + 1 > ngroups) ngroups = c_assign[j] + 1;
-    if (max_unique > 0 && ngroups > max_unique) {
-      // group scores = batch mean of logsumexp over the members' amplitudes (:373, :386)
-      float ps[FTN_KMAX];
-#pragma unroll
-      for (int g = 0; g < FTN_KMAX; ++g) ps[g] = 0.f;
-      for (int b = tid; b < B; b += 256) {
-        float a[FTN_KMAX];
-#pragma unroll
-        for (int j = 0; j < FTN_KMAX; ++j) a[j] = j < nsel ? rnd_act(med[(size_t)b * F + sd.sel_freq[j]], act_dtype) : 0.f;
-        for (int g = 0; g < ngroups; ++g) {
-          float mx = -INFINITY;
-#pragma unroll
-          for (int j = 0; j < FTN_KMAX; ++j) if (j < nsel && c_assign[j] == g) mx = fmaxf(mx, a[j]);
-          float se = 0.f;
-#pragma unroll
-          for (int j = 0; j < FTN_KMAX; ++j) if (j < nsel && c_assign[j] == g) se += expf(a[j] - mx);
-          ps[g] += rnd_act(logf(se) + mx, act_dtype);
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < FTN_KMAX; ++g) red[tid][g] = ps[g];
-      __syncthreads();
-      if (tid < FTN_KMAX) {
-        float t = 0.f;
-        for (int r = 0; r < 256; ++r) t += red[r][tid];
-        gscore[tid] = rnd_act(t / (float)B, act_dtype);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        // canonical period of each group = member with the largest column mean (first on ties, :374-378)
-        int gper[FTN_KMAX], keep[FTN_KMAX];
-        bool kept[FTN_KMAX];
-        for (int g = 0; g < ngroups; ++g) {
-          int best = -1;
-          for (int j = 0; j < nsel; ++j)
-            if (c_assign[j] == g && (best < 0 || colmean[j] > colmean[best])) best = j;
-          gper[g] = sd.sel_period[best];
-          kept[g] = false;
-        }
-        for (int r = 0; r < max_unique; ++r) {                    // top-k by score, descending, lowest id on ties
-          int best = -1;
-          for (int g = 0; g < ngroups; ++g)
-            if (!kept[g] && (best < 0 || gscore[g] > gscore[best])) best = g;
-          keep[r] = best; kept[best] = true;
-        }
-        int target[FTN_KMAX];
-        for (int g = 0; g < ngroups; ++g) {
-          target[g] = g;
-          if (kept[g]) continue;
-          int bt = 0;
-          float bd = fabsf((float)gper[keep[0]] - (float)gper[g]);
-          for (int r = 1; r < max_unique; ++r) {                  // nearest kept period, first in keep order (:421-424)
-            const float dd = fabsf((float)gper[keep[r]] - (float)gper[g]);
-            if (dd < bd) { bd = dd; bt = r; }
-          }
-          target[g] = keep[bt];
-        }
-        for (int j = 0; j < nsel; ++j) if (c_assign[j] >= 0) c_assign[j] = target[c_assign[j]];
-      }
-      __syncthreads();
-    }
-    if (tid == 0) {
-      // final metadata (:439-511): group period = canonical member, groups ordered by (period, canonical index)
-      int gid[FTN_KMAX], gcan[FTN_KMAX], G = 0;
-      for (int j = 0; j < nsel; ++j) {
-        if (c_assign[j] < 0) continue;
-        bool seen = false;
-        for (int g = 0; g < G; ++g) if (gid[g] == c_assign[j]) seen = true;
-        if (!seen) gid[G++] = c_assign[j];
-      }
-      for (int g = 0; g < G; ++g) {
-        int best = -1;
-        for (int j = 0; j < nsel; ++j)
-          if (c_assign[j] == gid[g] && (best < 0 || colmean[j] > colmean[best])) best = j;
-        gcan[g] = best;
-      }
-      for (int a_ = 1; a_ < G; ++a_) {                            // insertion sort by (period, canonical index)
-        const int vg = gid[a_], vc = gcan[a_];
-        int b_ = a_ - 1;
-        while (b_ >= 0 && (sd.sel_period[gcan[b_]] > sd.sel_period[vc] ||
-                           (sd.sel_period[gcan[b_]] == sd.sel_period[vc] && gcan[b_] > vc))) {
-          gid[b_ + 1] = gid[b_]; gcan[b_ + 1] = gcan[b_]; --b_;
-        }
-        gid[b_ + 1] = vg; gcan[b_ + 1] = vc;
-      }
-      int px = 0, tiles = 0;
-      for (int g = 0; g < FTN_KMAX; ++g) {
-        if (g < G) {
-          const int p = sd.sel_period[gcan[g]];
-          const int pad = (p - (L % p)) % p;
-          sd.g_period[g] = p; sd.g_pad[g] = pad; sd.g_cycles[g] = (L + pad) / p;
-          sd.g_px_off[g] = px; px += L + pad;
-          ftn_tile_geometry(sd.g_cycles[g], p, &sd.g_tw[g], &sd.g_th[g], &sd.g_ntx[g], &sd.g_nty[g]);
-          sd.g_tile_off[g] = tiles; tiles += sd.g_ntx[g] * sd.g_nty[g];
-        } else {
-          sd.g_period[g] = 0; sd.g_pad[g] = 0; sd.g_cycles[g] = 0;
-          sd.g_tw[g] = 0; sd.g_th[g] = 0; sd.g_ntx[g] = 0; sd.g_nty[g] = 0;
-          sd.g_px_off[g] = px; sd.g_tile_off[g] = tiles;
-        }
-      }
-      sd.g_px_off[FTN_KMAX] = px; sd.g_tile_off[FTN_KMAX] = tiles;
-      for (int j = 0; j < FTN_KMAX; ++j) {
-        int m = -1;
-        if (j < nsel && c_assign[j] >= 0)
-          for (int g = 0; g < G; ++g) if (gid[g] == c_assign[j]) m = g;
-        sd.sel_group[j] = m;
-      }
-      sd.n_groups = G; sd.total_px = px; sd.tiles_per_row = tiles;
-    }
-    __syncthreads();
-  }
-  // write the descriptor (whole struct, cooperatively)
-  {
-    const int* src = (const int*)&sd;
-    int* dst = (int*)desc;
-    for (int e = tid; e < (int)(sizeof(FtnDesc) / 4); e += 256) dst[e] = src[e];
-  }
-  // per-sample amplitudes and softmax-scatter weights            (:133-135, :992-1009)
-  const int nsel = sd.n_sel, G = sd.n_groups;
-  for (int b = tid; b < B; b += 256) {
-    float a[FTN_KMAX];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < FTN_KMAX; ++j) {
-      // unconditional load from a clamped index: a guarded load compiles to load + branch + wait per candidate
-      // (serialised memory round trips on this one-workgroup kernel's critical path)
-      const float mv = med[(size_t)b * F + (j < nsel ? sd.sel_freq[j] : 0)];
-      a[j] = (j < nsel) ? rnd_act(mv, act_dtype) : 0.f;
-      amps[(size_t)b * FTN_KMAX + j] = a[j];
-      if (j < nsel && sd.sel_group[j] >= 0) mx = fmaxf(mx, a[j]);
-    }
-    float w[FTN_KMAX];
-    float den = 0.f;
-#pragma unroll
-    for (int j = 0; j < FTN_KMAX; ++j) {
-      w[j] = 0.f;
-      if (j < nsel && sd.sel_group[j] >= 0) { a[j] = expf(a[j] - mx); den += a[j]; } else a[j] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < FTN_KMAX; ++j) {
-      if (j < nsel && sd.sel_group[j] >= 0) {
-        const float s = rnd_act(a[j] / den, act_dtype);
-        const int g = sd.sel_group[j];
-#pragma unroll
-        for (int gg = 0; gg < FTN_KMAX; ++gg) if (gg == g) w[gg] = rnd_act(w[gg] + s, act_dtype);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < FTN_KMAX; ++g) wts[(size_t)b * FTN_KMAX + g] = (g < G) ? w[g] : 0.f;
-  }
-}
+__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs fa) { finalize_body(fa); }
 
 extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B,
                                    int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
@@ -710,9 +356,9 @@ extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btota
   const int F = L / 2 + 1;
   const size_t lds = (size_t)F * sizeof(float);
   FTN_CHECK_ARG(lds <= 48 * 1024, "ftn_period_finalize: L=%d too long", L);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), lds, (hipStream_t)stream, psum_dev, nparts, Btotal, med_dev, B,
-                     L, F, k_periods, pmax, min_period_threshold, desc_dev, amps_dev, weights_dev, act_dtype,
-                     max_unique > 0 ? max_unique : 0, log_base > 1.0f ? log_base : 0.f);
+  FinalizeArgs fa = {psum_dev, nparts, Btotal, med_dev, B, L, F, k_periods, pmax, min_period_threshold, desc_dev,
+                     amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0f ? log_base : 0.f};
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), lds, (hipStream_t)stream, fa);
   FTN_CHECK_LAUNCH();
   return 0;
 }

@@ -111,11 +111,12 @@ class FFTPeriodSelector(nn.Module):
         return self.k <= 0 or L <= 1 or C <= 0 or B <= 0 or min(self.pmax, max(1, L - 1)) < self.min_period_threshold
 
     def select_device(self, x: torch.Tensor, act_dtype: Optional[torch.dtype] = None,
-                      max_unique: Optional[int] = None, log_base: Optional[float] = None):
+                      max_unique: Optional[int] = None, log_base: Optional[float] = None, stage_a=None):
         """Run S1-S5 on the device; returns a ``runtime.Selection`` (or ``None`` when
         the selector is degenerate, reference :89-90,140-142).  ``act_dtype`` (default: ``x.dtype``) is the
         caller's activation dtype: for bf16 / fp16 the reference's roundings of scores, amplitudes and
-        softmax weights are applied (:124-159, :1000-1009)."""
+        softmax weights are applied (:124-159, :1000-1009).  ``stage_a=(plan, wblob)`` of the TimesBlock that
+        will consume the selection lets its first stage share the finalize launch (``runtime.finalize``)."""
         from .. import runtime
 
         if x.ndim != 3:
@@ -146,7 +147,8 @@ class FFTPeriodSelector(nn.Module):
             b_total = B * world          # equal shards (no host sync to learn otherwise)
             psum = parts
         sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold, adt,
-                               max_unique or 0, log_base or 0.0)
+                               max_unique or 0, log_base or 0.0,
+                               stage_a=None if stage_a is None else (xf, stage_a[0], stage_a[1]))
         self._pending = sel
         return sel
 
@@ -436,8 +438,10 @@ class TimesBlock(nn.Module):
         adt = runtime.ACT_DTYPE.get(x.dtype, 0)
         if adt != 0:
             norm = None                        # half inputs: the shell's LayerNorm runs outside (see forward)
+        wblob, plan = self._packed(x.device)
         if native:
-            sel = sel_mod.select_device(xf, act_dtype=x.dtype, max_unique=max_unique, log_base=log_base)
+            sel = sel_mod.select_device(xf, act_dtype=x.dtype, max_unique=max_unique, log_base=log_base,
+                                        stage_a=(plan, wblob))
             if sel is None:                                            # reference :796-797
                 self._last_raw_period_count = self._last_valid_period_count = self._last_group_count = 0
                 return unchanged()
@@ -466,7 +470,6 @@ class TimesBlock(nn.Module):
             if int(dh.n_groups) != grp.periods.numel():
                 raise RuntimeError("host grouping and descriptor disagree")
             sel = runtime.selection_from_host(dh, w, x.device)
-        wblob, plan = self._packed(x.device)
         y = runtime.timesblock_forward(xf, plan, wblob, sel, norm, adt)
         if _env_on("TIMESBLOCK_VEC_DISABLE"):
             # same kernels either way (the two reference paths are the same math, :866-953);

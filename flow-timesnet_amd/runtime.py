@@ -9,6 +9,7 @@ in ``libflowtimes_hip.so``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Tuple
 
 import torch
@@ -104,9 +105,15 @@ ACT_DTYPE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
 
 def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int, pmax: int,
-             min_thr: int, act_dtype: int = 0, max_unique: int = 0, log_base: float = 0.0) -> Selection:
+             min_thr: int, act_dtype: int = 0, max_unique: int = 0, log_base: float = 0.0,
+             stage_a=None) -> Selection:
     """S3-S5 on the device.  ``psum`` is [F] or [nparts, F] (multi-GPU partial sums); ``act_dtype`` 1 / 2
-    applies the reference's bf16 / fp16 roundings of scores, amplitudes and weights."""
+    applies the reference's bf16 / fp16 roundings of scores, amplitudes and weights.
+
+    ``stage_a=(x, plan, wblob)``: the block that consumes this selection is known, so its stage A
+    (a = W_in1 x + b, independent of the selection) rides in the same launch
+    (``ftn_period_finalize_stage_a``); the returned Selection then owns the block's workspace and
+    ``timesblock_forward`` skips stage A."""
     lib = _lib.load()
     B = med.shape[0]
     dev = med.device
@@ -114,15 +121,30 @@ def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int
     desc = torch.empty(DESC_INTS, dtype=torch.int32, device=dev)
     amps = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
     wts = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
-    check(lib.ftn_period_finalize(_ptr(psum), nparts, int(b_total), _ptr(med), B, L, int(k), int(pmax),
-                                  int(min_thr), int(act_dtype), int(max_unique or 0), float(log_base or 0.0), _ptr(desc),
-                                  _ptr(amps), _ptr(wts), _stream(dev)),
-          "ftn_period_finalize")
     mg = C.c_int(0)
     pxb = lib.ftn_selector_px_bound(L, int(k), int(pmax), int(min_thr), C.byref(mg))
     if pxb < 0:
         check(pxb, "ftn_selector_px_bound")
-    return Selection(desc, amps, wts, max(1, int(mg.value)), int(pxb))
+    sel = Selection(desc, amps, wts, max(1, int(mg.value)), int(pxb))
+    if stage_a is not None and stage_a[1].mode == 0 and os.getenv("FTN_FUSE_STAGE_A", "1") != "0":
+        x, plan, wblob = stage_a
+        need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, sel.max_groups, sel.px_bound)
+        if need == 0:
+            raise ValueError(f"ftn_timesblock_workspace_bytes rejected the shape (B={B}, L={L})")
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        check(lib.ftn_period_finalize_stage_a(_ptr(psum), nparts, int(b_total), _ptr(med), B, L, int(k), int(pmax),
+                                              int(min_thr), int(act_dtype), int(max_unique or 0),
+                                              float(log_base or 0.0), _ptr(desc), _ptr(amps), _ptr(wts), _ptr(x),
+                                              C.byref(plan), _ptr(wblob), sel.max_groups, sel.px_bound, _ptr(ws),
+                                              ws.numel(), _stream(dev)),
+              "ftn_period_finalize_stage_a")
+        sel.stage_a = (ws, x.data_ptr(), C.addressof(plan))
+        return sel
+    check(lib.ftn_period_finalize(_ptr(psum), nparts, int(b_total), _ptr(med), B, L, int(k), int(pmax),
+                                  int(min_thr), int(act_dtype), int(max_unique or 0), float(log_base or 0.0), _ptr(desc),
+                                  _ptr(amps), _ptr(wts), _stream(dev)),
+          "ftn_period_finalize")
+    return sel
 
 
 def selection_from_host(desc_host: FtnDesc, weights: torch.Tensor, device: torch.device) -> Selection:
@@ -151,19 +173,29 @@ def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel:
         raise ValueError(f"ftn_timesblock_workspace_bytes rejected the shape (B={B}, L={L})")
     # one workspace per call, from the caching allocator: ordered on the calling stream, private to a graph
     # capture's pool, never shared between calls in flight (a process-wide buffer would be)
-    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    flags = 0
+    pre = getattr(sel, "stage_a", None)
+    if pre is not None:
+        # the selector's finalize launch already ran stage A for THIS x and plan into a workspace it allocated
+        ws, x_ptr, plan_addr = pre
+        sel.stage_a = None
+        if x_ptr != x.data_ptr() or plan_addr != C.addressof(plan) or ws.numel() < need:
+            raise RuntimeError("selection carries stage A of a different input or plan")
+        flags = 1   # FTN_FWD_STAGE_A_DONE
+    else:
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     y = torch.empty_like(x)
     if norm is not None:
         g, b, eps = norm
         check(lib.ftn_timesblock_forward_norm(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
-                                              _ptr(sel.weights), sel.max_groups, sel.px_bound, _ptr(g), _ptr(b),
+                                              _ptr(sel.weights), sel.max_groups, sel.px_bound, flags, _ptr(g), _ptr(b),
                                               float(eps),
                                               _ptr(ws), ws.numel(), _stream(x.device)),
               "ftn_timesblock_forward_norm")
         return y
     check(lib.ftn_timesblock_forward(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
-                                     _ptr(sel.weights), sel.max_groups, sel.px_bound, int(act_dtype), _ptr(ws), ws.numel(),
-                                     _stream(x.device)), "ftn_timesblock_forward")
+                                     _ptr(sel.weights), sel.max_groups, sel.px_bound, int(act_dtype), flags, _ptr(ws),
+                                     ws.numel(), _stream(x.device)), "ftn_timesblock_forward")
     return y
 
 

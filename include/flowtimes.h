@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTN_ABI_VERSION 7
+#define FTN_ABI_VERSION 8
 #define FTN_KMAX 16      /* max period candidates / groups per block call        */
 #define FTN_MAXBR 8      /* max kernels in kernel_set                             */
 
@@ -182,18 +182,30 @@ size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max
  * desc/weights are device pointers.  act_dtype (0 fp32, 1 bf16, 2 fp16) = dtype of the caller's activations:
  * x_dev / y_dev are always fp32 buffers (the caller up-casts, as the reference does for its convs, :1047-1052),
  * and for a half dtype every per-group delta, each weighted term, their sum and x + sum are rounded to it
- * exactly where the reference rounds them (:1068-1069, :1092, :818), so y holds values of that dtype. */
+ * exactly where the reference rounds them (:1068-1069, :1092, :818), so y holds values of that dtype.
+ * flags: FTN_FWD_STAGE_A_DONE = ftn_period_finalize_stage_a already ran stage A into this workspace. */
+#define FTN_FWD_STAGE_A_DONE 1
 int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                           int max_groups, int px_bound, int act_dtype, void* ws_dev, size_t ws_bytes,
+                           int max_groups, int px_bound, int act_dtype, int flags, void* ws_dev, size_t ws_bytes,
                            void* stream);
+/* ftn_period_finalize and stage A of the block (a = W_in1 x + b per window position, which does not depend on the
+ * selector) in ONE launch: workgroup 0 is the finalize kernel and then publishes the sanitised descriptor copy at
+ * the head of the workspace, the other workgroups compute stage A - the selector's single-workgroup tail (~17 us)
+ * no longer leaves the chip idle.  Same plan / workspace / bounds as the ftn_timesblock_forward call that
+ * follows with FTN_FWD_STAGE_A_DONE.  Bottleneck-mode plans only (mode 0). */
+int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B, int L,
+                                int k_periods, int pmax, int min_period_threshold, int act_dtype, int max_unique,
+                                float log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
+                                const float* x_dev, const FtnPlan* plan, const float* wblob_dev, int max_groups,
+                                int px_bound, void* ws_dev, size_t ws_bytes, void* stream);
 /* The same call followed by the caller's per-block epilogue of TimesNet.forward (:2050-2058, eval mode):
  *   y = LayerNorm_C( x + (block(x) - x) ; gamma, beta, eps )
  * fused into the last kernel when d_model <= 64 (bottleneck mode), one extra in-place row pass otherwise. */
 int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                 const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
-                                int max_groups, int px_bound, const float* ln_gamma_dev, const float* ln_beta_dev,
-                                float ln_eps, void* ws_dev, size_t ws_bytes, void* stream);
+                                int max_groups, int px_bound, int flags, const float* ln_gamma_dev,
+                                const float* ln_beta_dev, float ln_eps, void* ws_dev, size_t ws_bytes, void* stream);
 /* out[row][:] = LayerNorm_C( x[row][:] + (new[row][:] - x[row][:]) ) for rows x C fp32 matrices (in place
  * allowed: out == new).  Used when a block returns x unchanged (no valid period, :796-797). */
 int ftn_residual_layernorm(const float* x_dev, const float* new_dev, float* out_dev, long long rows, int C,

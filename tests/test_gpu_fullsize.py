@@ -246,8 +246,51 @@ def test_descriptor_beyond_declared_bounds_is_identity(ftn, dev):
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         y = torch.full_like(x, float("nan"))
         ftn.lib.check(lib.ftn_timesblock_forward(x.data_ptr(), y.data_ptr(), B, L, ctypes.byref(plan),
-                                                 wblob.data_ptr(), sel.desc.data_ptr(), sel.weights.data_ptr(), mg, pxb, 0,
+                                                 wblob.data_ptr(), sel.desc.data_ptr(), sel.weights.data_ptr(), mg, pxb, 0, 0,
                                                  ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
                       "ftn_timesblock_forward")
         torch.cuda.synchronize()
         assert torch.equal(y, x)
+
+
+# ---- stage A in the selector's finalize launch (ftn_period_finalize_stage_a) --------------------------------
+@pytest.mark.parametrize("engine", ["f32", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("B,L,C", [(16, 336, 64), (5, 97, 24)])
+def test_fused_finalize_stage_a_equals_two_launches(B, L, C, engine, ftn, dev, monkeypatch):
+    """The block's stage A rides in the finalize launch (workgroup 0 = S3-S5 + descriptor copy, the rest =
+    stage A).  Descriptor, amplitudes, weights and the block output must equal the separate launches bit for bit."""
+    rt = ftn.runtime
+    torch.manual_seed(3)
+    blk = ftn.models.TimesBlock(d_model=C, d_ff=2 * C, kernel_set=[(3, 3), (5, 5)], dropout=0.0, activation="gelu",
+                                bottleneck_ratio=4.0).to(dev).eval()
+    blk.engine = engine
+    blk.period_selector = ftn.models.FFTPeriodSelector(4, L, 1)
+    x = torch.from_numpy(ftn.synth.make_input(B, L, C, seed=9, planted=(24, 7))).to(dev)
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("FTN_FUSE_STAGE_A", fuse)
+        wblob, plan = blk._packed(dev)
+        sel = blk.period_selector.select_device(x, stage_a=(plan, wblob))
+        assert (getattr(sel, "stage_a", None) is not None) == (fuse == "1")
+        y = rt.timesblock_forward(x, plan, wblob, sel)
+        assert getattr(sel, "stage_a", None) is None
+        with torch.inference_mode():
+            y2 = blk(x)
+        assert blk._last_backend == "hip"
+        outs.append((sel.desc.cpu(), sel.amps.cpu(), sel.weights.cpu(), y.cpu(), y2.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][3], outs[0][4])
+    assert not torch.equal(outs[0][3], x.cpu())
+
+
+def test_fused_stage_a_rejects_a_foreign_input(ftn, dev):
+    rt = ftn.runtime
+    blk = ftn.models.TimesBlock(d_model=16, d_ff=32, kernel_set=[(3, 3)], dropout=0.0, activation="gelu",
+                                bottleneck_ratio=2.0).to(dev).eval()
+    blk.period_selector = ftn.models.FFTPeriodSelector(2, 48, 1)
+    x = torch.from_numpy(ftn.synth.make_input(2, 48, 16, seed=1)).to(dev)
+    wblob, plan = blk._packed(dev)
+    sel = blk.period_selector.select_device(x, stage_a=(plan, wblob))
+    with pytest.raises(RuntimeError, match="different input"):
+        rt.timesblock_forward(x.clone(), plan, wblob, sel)
