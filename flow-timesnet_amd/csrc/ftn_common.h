@@ -139,19 +139,21 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
 // matters: per value 3.2 full-rate-equivalent pk_fma + v_min + v_max + v_fma + v_exp = ~32 issue cycles.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 gelu_erf2(f2 v) {
-  f2 a, e, r;
-  a.x = fminf(fabsf(v.x), 8.0f);
-  a.y = fminf(fabsf(v.y), 8.0f);
-  f2 p = a * -3.262207974330522e-05f + 0.0007656298694200814f;
-  p = p * a + -0.008070714771747589f;
-  p = p * a + 0.05339965224266052f;
-  p = p * a + 0.45877760648727417f;
-  p = p * a + 1.1512006521224976f;
-  p = p * a + 0.9999929666519165f;
+  // the polynomial runs on n = -a (odd coefficients sign-flipped: the same Horner values bit for bit), so the last
+  // step is a plain fma(n, e, max(v, 0)) - hipcc otherwise negates a with two v_xor per pair instead of neg modifiers
+  f2 n, e, r;
+  n.x = fmaxf(-fabsf(v.x), -8.0f);
+  n.y = fmaxf(-fabsf(v.y), -8.0f);
+  f2 p = n * -3.262207974330522e-05f + -0.0007656298694200814f;
+  p = p * n + -0.008070714771747589f;
+  p = p * n + -0.05339965224266052f;
+  p = p * n + 0.45877760648727417f;
+  p = p * n + -1.1512006521224976f;
+  p = p * n + 0.9999929666519165f;
   e.x = __builtin_amdgcn_exp2f(-p.x);                         // raw v_exp_f32
   e.y = __builtin_amdgcn_exp2f(-p.y);
-  r.x = fmaf(-a.x, e.x, fmaxf(v.x, 0.0f));
-  r.y = fmaf(-a.y, e.y, fmaxf(v.y, 0.0f));
+  r.x = fmaf(n.x, e.x, fmaxf(v.x, 0.0f));
+  r.y = fmaf(n.y, e.y, fmaxf(v.y, 0.0f));
   return r;
 }
 __device__ __forceinline__ float gelu_erf(float v) { return gelu_erf2(f2{v, v}).x; }
@@ -233,17 +235,24 @@ __device__ __forceinline__ f4 mfma_h(bf8 a, bf8 b, f4 c) {
 
 #define FTN_H2_LOSCALE 2048.0f
 
-// NV (even) fp32 values -> hi and lo' piece vectors, NV/2 dwords each (v_cvt_pk_f16_f32: round to nearest even)
+// NV (even) fp32 values -> hi and lo' piece vectors, NV/2 dwords each (v_cvt_pk_f16_f32: round to nearest even).
+// lo' = fp16((v - hi) * 2^11) is formed as fma(hi, -2^11, v * 2^11) by v_fma_mixlo/mixhi_f16, which read the fp16
+// hi straight out of the packed dword and round the fp32 result to fp16 themselves: per PAIR of values one
+// v_cvt_pk, one v_pk_mul and two v_fma_mix instead of 2 v_cvt back + 2 subtract + 2 multiply + a second v_cvt_pk
+// (8 -> 4 VALU).  Same value bit for bit: v * 2^11 and hi * 2^11 are exact, their difference is the exact
+// (v - hi) * 2^11 (<= 13 significant bits), and both forms round it to fp16 once, to nearest even.
 template <int NV>
 __device__ __forceinline__ void split_h2(const float (&v)[NV], unsigned (&out)[2][NV / 2]) {
 #pragma unroll
   for (int k = 0; k < NV / 2; ++k) {
     const h2v hi = {(_Float16)v[2 * k], (_Float16)v[2 * k + 1]};
-    const float r0 = (v[2 * k] - (float)hi[0]) * FTN_H2_LOSCALE;
-    const float r1 = (v[2 * k + 1] - (float)hi[1]) * FTN_H2_LOSCALE;
-    const h2v lo = {(_Float16)r0, (_Float16)r1};
-    out[0][k] = __builtin_bit_cast(unsigned, hi);
-    out[1][k] = __builtin_bit_cast(unsigned, lo);
+    const unsigned hw = __builtin_bit_cast(unsigned, hi);
+    const f2 big = f2{v[2 * k], v[2 * k + 1]} * FTN_H2_LOSCALE;
+    unsigned lw;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(hw), "s"(-FTN_H2_LOSCALE), "v"(big.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hw), "s"(-FTN_H2_LOSCALE), "v"(big.y));
+    out[0][k] = hw;
+    out[1][k] = lw;
   }
 }
 
