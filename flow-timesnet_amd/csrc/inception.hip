@@ -37,6 +37,7 @@ static unsigned long long* g_stamp_buf = nullptr;
 static size_t g_stamp_cap = 0;
 static int g_stamp_which = 0;  // 1: k_conv, 2: k_mlp
 static const bool g_conv_generic = [] { const char* e = getenv("FTN_CONV_GENERIC"); return e != nullptr && e[0] == '1'; }();  // experiment switch
+static const bool g_mlp_pfd2 = [] { const char* e = getenv("FTN_MLP_PFD"); return e != nullptr && e[0] == '2'; }();   // experiment: fragment reads two steps ahead
 static const bool g_mlp_w16 = [] { const char* e = getenv("FTN_MLP_W16"); return e != nullptr && e[0] == '1'; }();   // experiment: 16-wave double-buffered k_mlp_bf_u1
 static const bool g_mlp_w4 = [] { const char* e = getenv("FTN_MLP_W4"); return e != nullptr && e[0] == '1'; }();     // experiment: 4-wave workgroups, three per CU
 static const bool g_mlp_u1 = [] { const char* e = getenv("FTN_MLP_U1"); return e == nullptr || e[0] != '0'; }();    // 0: the two-unit k_mlp_bf
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
 // MI355X_MICROARCH.md 'ldsdma-fill') makes that stream alone ~190 us of a 250 us launch.  256-pixel tiles halve
 // it, and with only one workgroup per CU the second buffer fits, so chunk c+1 lands while chunk c is computed
 // (one barrier per chunk instead of two around an exposed refill).  NWV = 8: two single-buffered workgroups per CU.
-template <int ACT, bool XVEC, int NS, int SKM, int SCP, int OTM, int NWV>
+template <int ACT, bool XVEC, int NS, int SKM, int SCP, int OTM, int NWV, int PFD = 1>
 __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void k_mlp_bf_u1(MlpBfArgs a) {
   constexpr int NFR = 2 * SKM + 2 * SCP + OTM;
   constexpr int NBUF = NWV == 16 ? 2 : 1;
@@ -914,17 +915,21 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
     if (active) {
       f4 h[2] = {bo_t[0], bo_t[1]};
       bf8 hp[NS];
-      bf8 fr[2][NWP];
+      // fragment reads run PFD steps ahead of their MFMAs in a ring of PFD + 1 register sets (PFD = 2 where the
+      // registers allow): one step (3 MFMAs + its share of the GELUs) is shorter than an LDS read's latency when
+      // sixteen waves stream fragments at once
+      bf8 fr[PFD + 1][NWP];
       auto ldfrag = [&](int f, bf8 (&ap)[NWP]) {
 #pragma unroll
         for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(wl + (size_t)(f * 3 + pz) * 1024);
       };
-      ldfrag(0, fr[0]);
+#pragma unroll
+      for (int f = 0; f < PFD; ++f) ldfrag(f, fr[f]);
 #pragma unroll
       for (int f = 0; f < NFR; ++f) {
-        if (f + 1 < NFR) ldfrag(f + 1, fr[(f + 1) & 1]);
+        if (f + PFD < NFR) ldfrag(f + PFD, fr[(f + PFD) % (PFD + 1)]);
         __builtin_amdgcn_sched_barrier(0);
-        const bf8 (&cur)[NWP] = fr[f & 1];
+        const bf8 (&cur)[NWP] = fr[f % (PFD + 1)];
         if (f < SKM) h[0] = chain_bf<NS>(cur, mp[f], h[0]);                         // layer 1, hidden tile 0
         else if (f < 2 * SKM) h[1] = chain_bf<NS>(cur, mp[f - SKM], h[1]);          // layer 1, hidden tile 1
         else if (f < 2 * SKM + SCP) h[0] = chain_bf<NS>(cur, xp[f - 2 * SKM], h[0]);               // + res1(x)
@@ -963,17 +968,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
   }
 }
 
-template <int ACT, int NS, int SKM, int SCP, int OTM, int NWV>
+template <int ACT, int NS, int SKM, int SCP, int OTM, int NWV, int PFD = 1>
 static int launch_mlp_bf_u1w(MlpBfArgs ma, bool xvec, long long Nmax, hipStream_t st) {
   ma.dbg = nullptr; ma.dbg_cap = 0;
   const size_t lds = (size_t)ma.per_chunk * 3 * 1024 * (NWV == 16 ? 2 : 1) + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
   if (lds > 160 * 1024) { ftn_set_error("stage C needs %zu B of LDS", lds); return -1; }
   const int nblk = (int)((Nmax + NWV * 16 - 1) / (NWV * 16));
-  hipError_t e = xvec ? hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                      : hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = xvec ? hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV, PFD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                      : hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV, PFD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_bf_u1): %s", hipGetErrorString(e)); return (int)e; }
-  if (xvec) hipLaunchKernelGGL((k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
-  else hipLaunchKernelGGL((k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
+  if (xvec) hipLaunchKernelGGL((k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV, PFD>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
+  else hipLaunchKernelGGL((k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV, PFD>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
   FTN_CHECK_LAUNCH();
   return 0;
 }
@@ -985,6 +990,9 @@ static int launch_mlp_bf_u1(const MlpBfArgs& ma, bool xvec, long long Nmax, hipS
     return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 16>(ma, xvec, Nmax, st);
   if (g_mlp_w4 && ((size_t)ma.per_chunk * 3 * 1024 + (size_t)ma.n_hchunks * 256) * 3 <= 160 * 1024)
     return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 4>(ma, xvec, Nmax, st);
+  if constexpr (NS == 2 && OTM <= 7) {
+    if (g_mlp_pfd2) return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 8, 2>(ma, xvec, Nmax, st);
+  }
   return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 8>(ma, xvec, Nmax, st);
 }
 
