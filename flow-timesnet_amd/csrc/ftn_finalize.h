@@ -44,7 +44,8 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
   extern __shared__ __attribute__((aligned(16))) float score[];  // [F]
   __shared__ int sel_idx[FTN_KMAX];
   __shared__ FtnDesc sd;
-  __shared__ float red[256][FTN_KMAX + 1];                        // block reductions of the flagged grouping
+  __shared__ float red[256][FTN_KMAX + 1];                        // block reductions of the flagged grouping; per-row scratch
+  __shared__ float wred[256][FTN_KMAX + 1];
   __shared__ float colmean[FTN_KMAX], gscore[FTN_KMAX];
   __shared__ int c_assign[FTN_KMAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -342,37 +343,40 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
     for (int e = tid; e < (int)(sizeof(FtnDesc) / 4); e += 256) dst[e] = src[e];
   }
   // per-sample amplitudes and softmax-scatter weights            (:133-135, :992-1009)
+  // One thread per batch row, its candidate values in its own LDS row (17-float stride: conflict-free).  This is a
+  // single-workgroup kernel on the critical path of every block call and it runs with a cold instruction cache:
+  // what it costs is code BYTES fetched, not instructions executed - the fully unrolled, predicated 16-slot form
+  // of this section (16 inlined expf, 16 divisions, a 16 x 16 select scatter) was 9 us of a 19 us launch.  So the
+  // gathers are issued together (unrolled, they are one instruction each) and everything else is a rolled loop
+  // over the nsel live candidates.
   const int nsel = sd.n_sel, G = sd.n_groups;
   for (int b = tid; b < B; b += 256) {
-    float a[FTN_KMAX];
+    const float* __restrict__ row = med + (size_t)b * F;
+    float* __restrict__ ar = red[tid];
+    float* __restrict__ wr = wred[tid];
+    float av[FTN_KMAX];
+#pragma unroll
+    for (int j = 0; j < FTN_KMAX; ++j) av[j] = row[j < nsel ? sd.sel_freq[j] : 0];   // clamped, unconditional
+#pragma unroll
+    for (int j = 0; j < FTN_KMAX; ++j) { ar[j] = av[j]; wr[j] = 0.f; }
     float mx = -INFINITY;
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < FTN_KMAX; ++j) {
-      // unconditional load from a clamped index: a guarded load compiles to load + branch + wait per candidate
-      // (serialised memory round trips on this one-workgroup kernel's critical path)
-      const float mv = med[(size_t)b * F + (j < nsel ? sd.sel_freq[j] : 0)];
-      a[j] = (j < nsel) ? rnd_act(mv, act_dtype) : 0.f;
-      amps[(size_t)b * FTN_KMAX + j] = a[j];
-      if (j < nsel && sd.sel_group[j] >= 0) mx = fmaxf(mx, a[j]);
+      const float v = j < nsel ? rnd_act(ar[j], act_dtype) : 0.f;
+      ar[j] = v;
+      amps[(size_t)b * FTN_KMAX + j] = v;
+      if (j < nsel && sd.sel_group[j] >= 0) mx = fmaxf(mx, v);
     }
-    float w[FTN_KMAX];
     float den = 0.f;
-#pragma unroll
-    for (int j = 0; j < FTN_KMAX; ++j) {
-      w[j] = 0.f;
-      if (j < nsel && sd.sel_group[j] >= 0) { a[j] = expf(a[j] - mx); den += a[j]; } else a[j] = 0.f;
+#pragma unroll 1
+    for (int j = 0; j < nsel; ++j)
+      if (sd.sel_group[j] >= 0) { const float e = expf(ar[j] - mx); ar[j] = e; den += e; }
+#pragma unroll 1
+    for (int j = 0; j < nsel; ++j) {
+      const int g = sd.sel_group[j];
+      if (g >= 0) wr[g] = rnd_act(wr[g] + rnd_act(ar[j] / den, act_dtype), act_dtype);
     }
-#pragma unroll
-    for (int j = 0; j < FTN_KMAX; ++j) {
-      if (j < nsel && sd.sel_group[j] >= 0) {
-        const float s = rnd_act(a[j] / den, act_dtype);
-        const int g = sd.sel_group[j];
-#pragma unroll
-        for (int gg = 0; gg < FTN_KMAX; ++gg) if (gg == g) w[gg] = rnd_act(w[gg] + s, act_dtype);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < FTN_KMAX; ++g) wts[(size_t)b * FTN_KMAX + g] = (g < G) ? w[g] : 0.f;
+#pragma unroll 1
+    for (int g = 0; g < FTN_KMAX; ++g) wts[(size_t)b * FTN_KMAX + g] = (g < G) ? wr[g] : 0.f;
   }
 }
-

@@ -2734,6 +2734,7 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
   FTN_CHECK_ARG(psum_dev && med_dev && desc_dev && amps_dev && weights_dev && x_dev && plan && wblob_dev && ws_dev,
                 "ftn_period_finalize_stage_a: null pointer");
   FTN_CHECK_ARG(B >= 1 && B <= 65535 && L >= 2 && nparts >= 1 && Btotal >= B, "ftn_period_finalize_stage_a: bad shape");
+  FTN_CHECK_ARG((((uintptr_t)amps_dev | (uintptr_t)weights_dev) & 15) == 0, "ftn_period_finalize_stage_a: amps / weights must be 16-byte aligned");
   FTN_CHECK_ARG(k_periods <= FTN_KMAX && act_dtype >= 0 && act_dtype <= 2, "ftn_period_finalize_stage_a: k=%d act_dtype=%d", k_periods, act_dtype);
   FTN_CHECK_ARG(plan->mode == 0 && plan->MP > 0 && plan->MP % 16 == 0, "ftn_period_finalize_stage_a: bottleneck blocks only");
   FTN_CHECK_ARG(max_groups >= 1 && max_groups <= FTN_KMAX && px_bound >= 0, "ftn_period_finalize_stage_a: bounds");

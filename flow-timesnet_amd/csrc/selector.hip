@@ -154,6 +154,60 @@ __device__ __forceinline__ void wave_lower_median_x4(const float* __restrict__ r
   for (int r = 0; r < 4; ++r) m[r] = __shfl(v[r], t);
 }
 
+// The same 21-step network on NR independent rows, three issue slots per compare-exchange: the partner value comes
+// from a raw v_mov_b32_dpp (hipcc wraps update_dpp in a copy, a canonicalising v_max and min + max + select: 8 slots,
+// and chains its four rows through one temporary), and the exchange itself is ONE v_med3_f32 against -inf (keep the
+// smaller) or +inf (keep the larger) - a per-lane constant that depends on the step only and is shared by the rows.
+// Values are only permuted, so the median is the same bits as the other forms'.  NaN-free inputs (amplitudes).
+template <int J>
+__device__ __forceinline__ float lane_xor_raw(float v) {
+  float o;
+  if constexpr (J == 1) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+  else if constexpr (J == 2) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+  else if constexpr (J == 8) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+  else if constexpr (J == 4)
+    asm volatile("v_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(o) : "v"(v));
+  else o = __shfl_xor(v, J);
+  return o;
+}
+
+template <int K, int J, int NR>
+__device__ __forceinline__ void bitonic_step_med3(float (&v)[NR], int lane) {
+  const bool keepmin = ((lane & K) == 0) == ((lane & J) == 0);   // K == 64: ascending everywhere
+  const float sel = keepmin ? -INFINITY : INFINITY;
+  float o[NR];
+  // a DPP read needs two wait states after the VALU write of its source, and inline asm is opaque to hipcc's hazard
+  // pass: ONE s_nop 1 in front of the step's DPP group (fenced so nothing that writes v[] can slip in behind it)
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (J < 16) asm volatile("s_nop 1");
+#pragma unroll
+  for (int r = 0; r < NR; ++r) o[r] = lane_xor_raw<J>(v[r]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], o[r], sel);
+}
+
+template <int NR>
+__device__ __forceinline__ void wave_lower_median_rows(const float* __restrict__ base, int stride, int C, int lane,
+                                                       float (&m)[NR]) {
+  float v[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) v[r] = lane < C ? base[(size_t)r * stride + lane] : INFINITY;
+  bitonic_step_med3<2, 1, NR>(v, lane);
+  bitonic_step_med3<4, 2, NR>(v, lane); bitonic_step_med3<4, 1, NR>(v, lane);
+  bitonic_step_med3<8, 4, NR>(v, lane); bitonic_step_med3<8, 2, NR>(v, lane); bitonic_step_med3<8, 1, NR>(v, lane);
+  bitonic_step_med3<16, 8, NR>(v, lane); bitonic_step_med3<16, 4, NR>(v, lane); bitonic_step_med3<16, 2, NR>(v, lane);
+  bitonic_step_med3<16, 1, NR>(v, lane);
+  bitonic_step_med3<32, 16, NR>(v, lane); bitonic_step_med3<32, 8, NR>(v, lane); bitonic_step_med3<32, 4, NR>(v, lane);
+  bitonic_step_med3<32, 2, NR>(v, lane); bitonic_step_med3<32, 1, NR>(v, lane);
+  bitonic_step_med3<64, 32, NR>(v, lane); bitonic_step_med3<64, 16, NR>(v, lane); bitonic_step_med3<64, 8, NR>(v, lane);
+  bitonic_step_med3<64, 4, NR>(v, lane); bitonic_step_med3<64, 2, NR>(v, lane); bitonic_step_med3<64, 1, NR>(v, lane);
+  const int t = (C - 1) >> 1;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) m[r] = __shfl(v[r], t);
+}
+
 __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, int B, int L, int C,
                                                   const float* __restrict__ tab, int F, int FPAD,
                                                   float* __restrict__ med, int flat) {
@@ -292,6 +346,146 @@ __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, i
   }
 }
 
+// ---------------------------------------------------------------- S1 + S2, one batch row per workgroup
+// The same DFT and median with x[b] resident in LDS.  k_spectrum gives every (row, 32-bin block) its own
+// workgroup, so each of a row's bin blocks re-reads and re-folds x[b] with two dword loads per lane per k-step
+// beside the two twiddle loads: four vector-memory instructions per MFMA pair, as much time on the texture path as
+// on the matrix pipe.  Here ONE workgroup owns the row: it folds x[b] once into LDS (ce = x[tau] + x[L - tau],
+// co = x[tau] - x[L - tau], float4 loads), wave w takes (bin block w % nfb, channel tile w / nfb) and reads its B
+// operands with conflict-free ds_read_b32 - the only global loads left in the loop are the twiddles - and the
+// whole [FPAD][C] amplitude tile of the row stays in LDS for the medians.  Same MFMA sequence on the same
+// operands as k_spectrum: the result is bit-identical.  Needs (KT + 1) * CP * 8 + FPAD * (C + 1) * 4 bytes of LDS
+// and nfb * nct <= 16 waves (L = 336, C = 64: 136 KB, 12 waves = three per SIMD); other shapes keep k_spectrum.
+__global__ __launch_bounds__(1024) void k_spectrum_row(const float* __restrict__ x, int B, int L, int C,
+                                                       const float* __restrict__ tab, int F, int FPAD,
+                                                       float* __restrict__ med) {
+  extern __shared__ __attribute__((aligned(16))) float lds_row[];
+  const int KT = (L >> 1) + 1;                         // folded time steps tau = 0 .. L/2
+  const int KTP = (KT + 1) & ~1;                       // rows incl. the zero row an odd KT's last k-step reads
+  const int nct = (C + 31) >> 5, CP = nct * 32, CS = C + 1;
+  float* __restrict__ ce = lds_row;                    // [KTP][CP]
+  float* __restrict__ co = ce + (size_t)KTP * CP;      // [KTP][CP]
+  float* __restrict__ amp = co + (size_t)KTP * CP;     // [FPAD][CS]
+  const int b = blockIdx.x;
+  const int nfb = FPAD >> 5;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const float* __restrict__ xb = x + (size_t)b * L * C;
+  // ---- fold the row into LDS (same expressions as k_spectrum's step_guarded: bit-identical operands)
+  if ((C & 3) == 0 && (((uintptr_t)x) & 15) == 0) {
+    // four float4 pairs in flight per thread: a plain load -> fold -> store loop pays one HBM round trip per pass
+    const int c4n = CP >> 2, total = KTP * c4n;
+    for (int e0 = tid; e0 < total; e0 += 4 * nthr) {
+      f4 xv[4], xp[4];
+      int tau[4], c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * nthr;
+        tau[u] = e / c4n; c[u] = (e - tau[u] * c4n) * 4;
+        const bool ok = e < total && tau[u] < KT && c[u] < C;
+        const bool pair = ok && tau[u] > 0 && 2 * tau[u] < L;
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+        xv[u] = ok ? *(const f4*)(xb + (size_t)tau[u] * C + c[u]) : z;
+        xp[u] = pair ? *(const f4*)(xb + (size_t)(L - tau[u]) * C + c[u]) : z;
+        if (!pair) xp[u] = z;
+        tau[u] = pair ? tau[u] : -1 - tau[u];           // sign carries `pair` to the store loop
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * nthr;
+        if (e >= total) continue;
+        const bool pair = tau[u] >= 0;
+        const int t = pair ? tau[u] : -1 - tau[u];
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+        // pair: x[tau] + x[L - tau] and x[tau] - x[L - tau]; no partner (tau = 0, L/2) or padding: x[tau] (or 0) and 0
+        *(f4*)(ce + (size_t)t * CP + c[u]) = pair ? xv[u] + xp[u] : xv[u];
+        *(f4*)(co + (size_t)t * CP + c[u]) = pair ? xv[u] - xp[u] : z;
+      }
+    }
+  } else {
+    for (int e = tid; e < KTP * CP; e += nthr) {
+      const int tau = e / CP, c = e - tau * CP;
+      float ve = 0.f, vo = 0.f;
+      if (tau < KT && c < C) {
+        const bool pair = tau > 0 && 2 * tau < L;
+        const float xv = xb[(size_t)tau * C + c];
+        if (pair) { const float xp = xb[(size_t)(L - tau) * C + c]; ve = xv + xp; vo = xv - xp; }
+        else ve = xv;
+      }
+      ce[e] = ve; co[e] = vo;
+    }
+  }
+  __syncthreads();
+  // ---- DFT: wave -> (bin block, channel tile)
+  {
+    const int i = lane & 31, h = lane >> 5;
+    const int fbk = wave % nfb, ct = wave / nfb;
+    const int f0 = fbk * 32;
+    const int c = ct * 32 + i;
+    const float* __restrict__ pc = tab + f0 + i + (size_t)h * FPAD;
+    const float* __restrict__ ps = tab + (size_t)L * FPAD + f0 + i + (size_t)h * FPAD;
+    const float* __restrict__ pe = ce + (size_t)h * CP + c;
+    const float* __restrict__ po = co + (size_t)h * CP + c;
+    const int sT = 2 * FPAD, sX = 2 * CP;
+    const int nks = KTP >> 1;                          // k-steps (two folded samples each)
+    f16v re = {0}, im = {0};
+    // twiddle rows tau >= KT of an odd-KT last step meet zero operands; they are inside the table (KT < L for L >= 3)
+    float ac[8], as[8];
+    const int nblk = nks >> 3;
+    if (nblk > 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { ac[k] = pc[k * sT]; as[k] = ps[k * sT]; }
+    }
+    for (int it = 0; it < nblk; ++it) {
+      float an[8], sn[8], be[8], bo[8];
+      const bool more = it + 1 < nblk;
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { an[k] = pc[(8 * (it + 1) + k) * sT]; sn[k] = ps[(8 * (it + 1) + k) * sT]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { be[k] = pe[(8 * it + k) * sX]; bo[k] = po[(8 * it + k) * sX]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[k], be[k], re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k], bo[k], im, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ac[k] = an[k]; as[k] = sn[k]; }
+      }
+    }
+    for (int ks = nblk * 8; ks < nks; ++ks) {
+      const int tau = 2 * ks + h;
+      const float cv = tau < KT ? pc[(size_t)ks * sT] : 0.f;
+      const float sv = tau < KT ? ps[(size_t)ks * sT] : 0.f;
+      re = __builtin_amdgcn_mfma_f32_32x32x2f32(cv, pe[ks * sX], re, 0, 0, 0);
+      im = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, po[ks * sX], im, 0, 0, 0);
+    }
+    if (c < C) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int fi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        amp[(size_t)(f0 + fi) * CS + c] = hypotf(re[r], im[r]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- lower median over channels, four bins per wave pass
+  const int nw = nthr >> 6;
+  for (int fb = wave * 8; fb < F; fb += nw * 8) {       // rows fb .. fb + 7 (amp has FPAD >= fb + 8 rows)
+    float m[8];
+    wave_lower_median_rows<8>(amp + (size_t)fb * CS, CS, C, lane, m);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (fb + r < F) med[(size_t)b * F + fb + r] = m[r];
+    }
+  }
+}
+
 // psum[f] = sum_b med[b][f] in fp64, fixed order: 32 row-strided partial sums per column, combined in index
 // order (bitwise reproducible; no atomics).
 __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ med, int B, int F,
@@ -327,8 +521,21 @@ extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, cons
     if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
   }
   const int nfb = FPAD / 32;
-  hipLaunchKernelGGL(k_spectrum, dim3((unsigned)(ftn_cdiv(B, 8) * 8 * nfb)), dim3(64 * nw), lds, (hipStream_t)stream, x_dev,
-                     B, L, C, (const float*)table_dev, F, FPAD, med_dev, getenv("FTN_SEL_FLAT") != nullptr ? 1 : 0);
+  // row-resident form where the folded row and its amplitude tile fit LDS and there are rows enough to fill the chip
+  // (FTN_SEL_ROW=1 / 0 forces / forbids it: the two kernels are bit-identical, tests compare them)
+  const int KT = L / 2 + 1, KTP = (KT + 1) & ~1, nct = (C + 31) / 32;
+  const size_t lds_row = (size_t)KTP * nct * 32 * 8 + (size_t)FPAD * (C + 1) * sizeof(float);
+  static const int row_mode = [] { const char* e = getenv("FTN_SEL_ROW"); return e == nullptr ? -1 : (e[0] == '1' ? 1 : 0); }();
+  const bool row_fits = C <= 64 && nfb * nct <= 16 && lds_row <= 160 * 1024 && L >= 3;
+  if (row_fits && (row_mode == 1 || (row_mode < 0 && B >= 64))) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_spectrum_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
+    if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_spectrum_row): %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(k_spectrum_row, dim3((unsigned)B), dim3(64 * nfb * nct), lds_row, (hipStream_t)stream, x_dev, B, L, C,
+                       (const float*)table_dev, F, FPAD, med_dev);
+  } else {
+    hipLaunchKernelGGL(k_spectrum, dim3((unsigned)(ftn_cdiv(B, 8) * 8 * nfb)), dim3(64 * nw), lds, (hipStream_t)stream, x_dev,
+                       B, L, C, (const float*)table_dev, F, FPAD, med_dev, getenv("FTN_SEL_FLAT") != nullptr ? 1 : 0);
+  }
   FTN_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_colsum, dim3(ftn_cdiv(F, 32)), dim3(1024), 0, (hipStream_t)stream, med_dev, B, F, psum_dev);
   FTN_CHECK_LAUNCH();
@@ -345,6 +552,7 @@ extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btota
                                    int max_unique, float log_base, FtnDesc* desc_dev, float* amps_dev,
                                    float* weights_dev, void* stream) {
   FTN_CHECK_ARG(psum_dev && med_dev && desc_dev && amps_dev && weights_dev, "ftn_period_finalize: null pointer");
+  FTN_CHECK_ARG((((uintptr_t)amps_dev | (uintptr_t)weights_dev) & 15) == 0, "ftn_period_finalize: amps / weights must be 16-byte aligned");
   FTN_CHECK_ARG(B >= 1 && L >= 2 && nparts >= 1 && Btotal >= B, "ftn_period_finalize: bad shape");
   FTN_CHECK_ARG(k_periods <= FTN_KMAX, "ftn_period_finalize: k_periods=%d > FTN_KMAX=%d", k_periods, FTN_KMAX);
   FTN_CHECK_ARG(act_dtype >= 0 && act_dtype <= 2, "ftn_period_finalize: act_dtype=%d", act_dtype);

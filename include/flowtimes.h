@@ -140,13 +140,16 @@ size_t ftn_dft_table_bytes(int L);
 /* fill the table (cos/sin of 2*pi*f*t/L evaluated in fp64 on the device) */
 int ftn_dft_table_init(void* table_dev, int L, void* stream);
 /* S1+S2 (:108-112): med[b][f] = lower-median_c |rfft_t x[b,:,c]|_f, f < L/2+1,
- * psum[f] = sum_b med[b][f] (fp64, fixed order).  med: [B][F] dev, psum: [F] dev. */
+ * psum[f] = sum_b med[b][f] (fp64, fixed order).  med: [B][F] dev, psum: [F] dev.
+ * Two kernels, bit-identical results: one workgroup per (row, 32-bin block), or - when a row's folded samples
+ * and amplitude tile fit LDS (C <= 64, e.g. L = 336) and B >= 64 - one workgroup per row with x[b] resident in
+ * LDS.  FTN_SEL_ROW=1 / 0 in the environment forces / forbids the second form. */
 int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* table_dev,
                         float* med_dev, double* psum_dev, void* stream);
 /* S3-S5 (:119-157, PeriodGrouper.group :513-557, softmax/scatter :992-1009).
  * psum: [nparts][F] partial batch sums (summed in index order; nparts>1 is the
  * multi-GPU exchange of SURVEY §8e), Btotal = global batch.  Writes the
- * descriptor, amps[B][FTN_KMAX] and group weights w[B][FTN_KMAX].
+ * descriptor, amps[B][FTN_KMAX] and group weights w[B][FTN_KMAX] (both 16-byte aligned).
  * act_dtype: dtype of the caller's activations - 0 fp32, 1 bf16, 2 fp16.  For half inputs the reference
  * rounds the batch-mean spectrum and the scores (:124, :130), the returned amplitudes (:159), the softmax
  * weights (:1000) and their scatter-added group sums (:1009) to that dtype; the kernel applies the same
