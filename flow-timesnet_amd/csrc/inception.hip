@@ -1522,8 +1522,17 @@ __device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __r
     const int c1 = (t1 / KW) * RW32 + (t1 % KW) * CBF_PX_BYTES;
     const int toff = half1 ? c1 : c0;
     // weights first: the slab's first MFMA needs them, and LDS reads return in issue order
+    if constexpr (NS == 2) {
+      // A2 = A1 * 2^-11 exactly (an fp16 multiply by a power of two, subnormals included - the packer forms it the
+      // same way), so it is not read: LDS reads and MFMA time are level in this kernel (9 : 9 per slab), the VALU
+      // is not, and four v_pk_mul_f16 replace one ds_read_b128 of every slab
+      ap[0] = *(const bf8*)(wlane + (s * 3 + 0) * 1024);
+      ap[2] = *(const bf8*)(wlane + (s * 3 + 2) * 1024);
+      ap[1] = __builtin_bit_cast(bf8, __builtin_bit_cast(h8, ap[0]) * (_Float16)0.00048828125f);
+    } else {
 #pragma unroll
-    for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(wlane + (s * 3 + pz) * 1024);
+      for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(wlane + (s * 3 + pz) * 1024);
+    }
 #pragma unroll
     for (int u = 0; u < CBF_NU; ++u) {
       const int v = (int)__builtin_amdgcn_ubfe(vmask[u], (unsigned)s, 1u);
@@ -1542,12 +1551,13 @@ __device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __r
   // was exposed (the 4-bit lgkmcnt cannot express "all but the 18 newest").
   auto interleave = [&]() {
     static_assert(CBF_NU == 3, "interleave patterns are written for three pixel units per wave");
-    if constexpr (NS == 2) {                                  // 9 reads : 9 MFMAs
+    if constexpr (NS == 2) {                                  // 8 reads + 4 v_pk_mul_f16 : 9 MFMAs
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {                           // MFMA first: the wait in front of it then covers
+      for (int k = 0; k < 8; ++k) {                           // MFMA first: the wait in front of it then covers
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // only reads issued a whole slab earlier
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     } else if constexpr (NS == 3) {                           // 12 reads : 18 MFMAs
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
