@@ -17,9 +17,18 @@
 // and evaluated in fp64, so the fp32 table is correctly rounded.
 static inline int fpad_of(int L) { return ((L / 2 + 1) + 31) & ~31; }
 
+// Quarter-fold tables (L % 4 == 0), appended behind the two [L][FPAD] planes: for even bins f = 2m and odd bins
+// f = 2m + 1 the twiddles at tau = 0 .. L/4, four planes [QP][FQ]: cos even, sin even, cos odd, sin odd
+// (QP = L/4 + 1 rounded up to even, FQ = number of even bins rounded up to 32; zero outside).
+static inline int qfold_qp(int L) { return ((L / 4 + 1) + 1) & ~1; }
+static inline int qfold_fq(int L) { return (((L / 2 + 1) + 1) / 2 + 31) & ~31; }
+static inline bool qfold_ok(int L) { return L >= 8 && (L & 3) == 0; }
+
 extern "C" size_t ftn_dft_table_bytes(int L) {
   if (L < 2) return 0;
-  return (size_t)2 * L * fpad_of(L) * sizeof(float);
+  size_t n = (size_t)2 * L * fpad_of(L);
+  if (qfold_ok(L)) n += (size_t)4 * qfold_qp(L) * qfold_fq(L);
+  return n * sizeof(float);
 }
 
 __global__ void k_dft_table(float* __restrict__ tab, int L, int F, int FPAD) {
@@ -38,6 +47,24 @@ __global__ void k_dft_table(float* __restrict__ tab, int L, int F, int FPAD) {
   }
 }
 
+__global__ void k_dft_table_q(float* __restrict__ qt, int L, int F, int QP, int FQ) {
+  const int total = QP * FQ, Q = L / 4;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * total; e += gridDim.x * blockDim.x) {
+    const int odd = e >= total ? 1 : 0;
+    const int r = e - odd * total, t = r / FQ, m = r - t * FQ;
+    const int f = 2 * m + odd;
+    float c = 0.f, s = 0.f;
+    if (f < F && t <= Q) {
+      const long long k = ((long long)f * t) % L;
+      const double ang = 2.0 * (double)k / (double)L;
+      c = (float)cospi(ang);
+      s = (float)sinpi(ang);
+    }
+    qt[(size_t)(2 * odd) * total + r] = c;
+    qt[(size_t)(2 * odd + 1) * total + r] = s;
+  }
+}
+
 extern "C" int ftn_dft_table_init(void* table_dev, int L, void* stream) {
   FTN_CHECK_ARG(table_dev && L >= 2, "ftn_dft_table_init: bad table/L=%d", L);
   const int F = L / 2 + 1, FPAD = fpad_of(L);
@@ -45,6 +72,12 @@ extern "C" int ftn_dft_table_init(void* table_dev, int L, void* stream) {
   hipLaunchKernelGGL(k_dft_table, dim3(ftn_cdiv(total, 256) < 1024 ? ftn_cdiv(total, 256) : 1024), dim3(256), 0,
                      (hipStream_t)stream, (float*)table_dev, L, F, FPAD);
   FTN_CHECK_LAUNCH();
+  if (qfold_ok(L)) {
+    const int QP = qfold_qp(L), FQ = qfold_fq(L);
+    hipLaunchKernelGGL(k_dft_table_q, dim3(ftn_cdiv(2 * QP * FQ, 256) < 1024 ? ftn_cdiv(2 * QP * FQ, 256) : 1024), dim3(256), 0,
+                       (hipStream_t)stream, (float*)table_dev + (size_t)2 * total, L, F, QP, FQ);
+    FTN_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -486,6 +519,145 @@ __global__ __launch_bounds__(1024) void k_spectrum_row(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------- S1 + S2, row-resident, folded twice (L % 4 == 0)
+// With H = L/2 and theta = 2 pi f tau / L:  cos(2 pi f (H - tau) / L) = (-1)^f cos(theta) and
+// sin(2 pi f (H - tau) / L) = -(-1)^f sin(theta), so the half-folded sums of k_spectrum_row fold once more around
+// tau = L/4, separately for even and odd bins:
+//   even f:  Re = sum_{tau<=Q} ee[tau] cos,  ee = ce[tau] + ce[H - tau]      Im = sum eo[tau] sin,  eo = co[tau] - co[H - tau]
+//   odd  f:  Re = sum_{tau< Q} oe[tau] cos,  oe = ce[tau] - ce[H - tau]      Im = sum oo[tau] sin,  oo = co[tau] + co[H - tau]
+// (Q = L/4; at tau = Q: ee = ce[Q], oo = co[Q], eo = oe = 0 - the twiddles there vanish for that parity.)
+// Half the fp32 MFMAs of k_spectrum_row - the pipe that kernel is bound by - for two more adds per sample.  A
+// wave takes (parity, 32-bin block of that parity, channel tile).  Not bit-identical to the other two kernels
+// (the four-term sums round differently, at the 1e-7 level); ranks of a sharded batch all take the same path.
+__global__ __launch_bounds__(1024) void k_spectrum_rowq(const float* __restrict__ x, int B, int L, int C,
+                                                        const float* __restrict__ qtab, int F, int QP, int FQ,
+                                                        int amp_rows, float* __restrict__ med) {
+  extern __shared__ __attribute__((aligned(16))) float lds_row[];
+  const int H = L >> 1, Q = L >> 2;
+  const int nct = (C + 31) >> 5, CP = nct * 32, CS = C + 1;
+  const size_t plane = (size_t)QP * CP;
+  float* __restrict__ fold = lds_row;                  // [4][QP][CP]: ee, eo, oe, oo
+  float* __restrict__ amp = lds_row + 4 * plane;       // [amp_rows][CS]
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const float* __restrict__ xb = x + (size_t)b * L * C;
+  {
+    const bool vec = (C & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+    const int cw = vec ? 4 : 1, cn = CP / cw, total = QP * cn;
+    for (int e0 = tid; e0 < total; e0 += 2 * nthr) {
+      f4 x0[2], x1[2], x2[2], x3[2];                   // x[tau], x[L - tau], x[H - tau], x[H + tau]
+      int tau[2], c[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = e0 + u * nthr;
+        tau[u] = e / cn; c[u] = (e - tau[u] * cn) * cw;
+        const bool ok = e < total && tau[u] <= Q && c[u] < C;
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+        x0[u] = x1[u] = x2[u] = x3[u] = z;
+        if (ok) {
+          const int t = tau[u];
+          if (vec) {
+            x0[u] = *(const f4*)(xb + (size_t)t * C + c[u]);
+            if (t > 0) x1[u] = *(const f4*)(xb + (size_t)(L - t) * C + c[u]);
+            if (t < Q) { x2[u] = *(const f4*)(xb + (size_t)(H - t) * C + c[u]); if (t > 0) x3[u] = *(const f4*)(xb + (size_t)(H + t) * C + c[u]); }
+          } else {
+            x0[u].x = xb[(size_t)t * C + c[u]];
+            if (t > 0) x1[u].x = xb[(size_t)(L - t) * C + c[u]];
+            if (t < Q) { x2[u].x = xb[(size_t)(H - t) * C + c[u]]; if (t > 0) x3[u].x = xb[(size_t)(H + t) * C + c[u]]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = e0 + u * nthr;
+        if (e >= total) continue;
+        const int t = tau[u];
+        // ce[t] = x[t] + x[L-t] (t = 0: x[0]),  co[t] = x[t] - x[L-t] (t = 0: 0);  partner H - t: x[H-t] +- x[H+t]
+        // (t = 0: ce[H] = x[H], co[H] = 0; t = Q has no partner)
+        const f4 ce = x0[u] + x1[u];
+        const f4 co = t > 0 ? x0[u] - x1[u] : f4{0.f, 0.f, 0.f, 0.f};
+        const f4 pe = x2[u] + x3[u];
+        const f4 po = (t > 0 && t < Q) ? x2[u] - x3[u] : f4{0.f, 0.f, 0.f, 0.f};
+        f4 ee = ce + pe, eo = co - po, oe = ce - pe, oo = co + po;
+        if (t >= Q) { eo = f4{0.f, 0.f, 0.f, 0.f}; oe = f4{0.f, 0.f, 0.f, 0.f}; }
+        if (t > Q) { ee = f4{0.f, 0.f, 0.f, 0.f}; oo = f4{0.f, 0.f, 0.f, 0.f}; }
+        float* dst = fold + (size_t)t * CP + c[u];
+        if (vec) {
+          *(f4*)(dst) = ee; *(f4*)(dst + plane) = eo; *(f4*)(dst + 2 * plane) = oe; *(f4*)(dst + 3 * plane) = oo;
+        } else {
+          dst[0] = ee.x; dst[plane] = eo.x; dst[2 * plane] = oe.x; dst[3 * plane] = oo.x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int i = lane & 31, h = lane >> 5;
+    const int nfq = FQ >> 5;                           // 32-bin blocks per parity
+    const int blk = wave % (2 * nfq), ct = wave / (2 * nfq);
+    const int odd = blk >= nfq ? 1 : 0, m0 = (blk - odd * nfq) * 32;
+    const int c = ct * 32 + i;
+    const size_t tplane = (size_t)QP * FQ;
+    const float* __restrict__ pc = qtab + (size_t)(2 * odd) * tplane + (size_t)h * FQ + m0 + i;
+    const float* __restrict__ ps = pc + tplane;
+    const float* __restrict__ pe = fold + (size_t)(2 * odd) * plane + (size_t)h * CP + c;   // ee | oe
+    const float* __restrict__ po = fold + (size_t)(odd ? 3 : 1) * plane + (size_t)h * CP + c;   // eo | oo
+    const int sT = 2 * FQ, sX = 2 * CP;
+    const int nks = QP >> 1;
+    f16v re = {0}, im = {0};
+    float ac[8], as[8];
+    const int nblk = nks >> 3;
+    if (nblk > 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { ac[k] = pc[k * sT]; as[k] = ps[k * sT]; }
+    }
+    for (int it = 0; it < nblk; ++it) {
+      float an[8], sn[8], be[8], bo[8];
+      const bool more = it + 1 < nblk;
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { an[k] = pc[(8 * (it + 1) + k) * sT]; sn[k] = ps[(8 * (it + 1) + k) * sT]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { be[k] = pe[(8 * it + k) * sX]; bo[k] = po[(8 * it + k) * sX]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        re = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[k], be[k], re, 0, 0, 0);
+        im = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k], bo[k], im, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ac[k] = an[k]; as[k] = sn[k]; }
+      }
+    }
+    for (int ks = nblk * 8; ks < nks; ++ks) {
+      re = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[(size_t)ks * sT], pe[ks * sX], re, 0, 0, 0);
+      im = __builtin_amdgcn_mfma_f32_32x32x2f32(ps[(size_t)ks * sT], po[ks * sX], im, 0, 0, 0);
+    }
+    if (c < C) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int fi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        amp[(size_t)(2 * (m0 + fi) + odd) * CS + c] = hypotf(re[r], im[r]);
+      }
+    }
+  }
+  __syncthreads();
+  const int nw = nthr >> 6;
+  for (int fb = wave * 8; fb < F; fb += nw * 8) {       // rows fb .. fb + 7 < amp_rows
+    float m[8];
+    wave_lower_median_rows<8>(amp + (size_t)fb * CS, CS, C, lane, m);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (fb + r < F) med[(size_t)b * F + fb + r] = m[r];
+    }
+  }
+}
+
 // psum[f] = sum_b med[b][f] in fp64, fixed order: 32 row-strided partial sums per column, combined in index
 // order (bitwise reproducible; no atomics).
 __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ med, int B, int F,
@@ -525,9 +697,19 @@ extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, cons
   // (FTN_SEL_ROW=1 / 0 forces / forbids it: the two kernels are bit-identical, tests compare them)
   const int KT = L / 2 + 1, KTP = (KT + 1) & ~1, nct = (C + 31) / 32;
   const size_t lds_row = (size_t)KTP * nct * 32 * 8 + (size_t)FPAD * (C + 1) * sizeof(float);
-  static const int row_mode = [] { const char* e = getenv("FTN_SEL_ROW"); return e == nullptr ? -1 : (e[0] == '1' ? 1 : 0); }();
+  // FTN_SEL_ROW: 0 = k_spectrum, 1 = k_spectrum_row, 2 = k_spectrum_rowq, unset = fastest form that fits
+  static const int row_mode = [] { const char* e = getenv("FTN_SEL_ROW"); return e == nullptr ? -1 : atoi(e); }();
   const bool row_fits = C <= 64 && nfb * nct <= 16 && lds_row <= 160 * 1024 && L >= 3;
-  if (row_fits && (row_mode == 1 || (row_mode < 0 && B >= 64))) {
+  const int QP = qfold_qp(L), FQ = qfold_fq(L);
+  const int amp_rows = ((2 * FQ > FPAD ? 2 * FQ : FPAD) + 7) & ~7;
+  const size_t lds_q = (size_t)4 * QP * nct * 32 * sizeof(float) + (size_t)amp_rows * (C + 1) * sizeof(float);
+  const bool q_fits = qfold_ok(L) && C <= 64 && 2 * (FQ / 32) * nct <= 16 && lds_q <= 160 * 1024;
+  if (q_fits && (row_mode == 2 || (row_mode < 0 && B >= 64))) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_spectrum_rowq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_spectrum_rowq): %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(k_spectrum_rowq, dim3((unsigned)B), dim3(64 * 2 * (FQ / 32) * nct), lds_q, (hipStream_t)stream, x_dev, B, L,
+                       C, (const float*)table_dev + (size_t)2 * L * FPAD, F, QP, FQ, amp_rows, med_dev);
+  } else if (row_fits && (row_mode == 1 || (row_mode < 0 && B >= 64))) {
     hipError_t e = hipFuncSetAttribute((const void*)k_spectrum_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
     if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_spectrum_row): %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(k_spectrum_row, dim3((unsigned)B), dim3(64 * nfb * nct), lds_row, (hipStream_t)stream, x_dev, B, L, C,
