@@ -1506,6 +1506,23 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
 //     once per tile: bit s of vmask[u] = tap 2s + (lane half) is inside the grid for this lane's pixel;
 //   * the region planes sit CBF_FAST_PLANE bytes apart (a constant), so the second piece is a ds_read offset.
 // That leaves ~10 VALU per slab: v_bfe, v_add, v_mad per pixel unit and one select for the tap offset.
+// Workgroup barrier that waits only until at most `keep` of this wave's vector-memory operations are still in
+// flight (vmcnt retires in issue order on gfx9, loads and stores alike): the conv row loop issues
+//   LDS-DMA of row b+1 | compute row b | output stores of row b
+// and the next barrier needs the DMA, not the stores - a plain __syncthreads() waits vmcnt(0), i.e. one HBM write
+// round trip per batch row.  `keep` is wave-uniform.
+__device__ __forceinline__ void barrier_keep_vm(int keep) {
+  switch (keep) {
+    case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  }
+}
+
 #define CBF_FAST_PLANE (FTN_REGION_PX * CBF_PX_BYTES + 64)
 
 template <int NS, int KH, int KW>
@@ -1660,21 +1677,46 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
     const float inv_tw = 1.0f / (float)tw, inv_rw = 1.0f / (float)RW;
     const int nchunks16 = RH * RW * 2;
     const int ppp = (nchunks16 + 63) >> 6;
+    // descriptor values the row loop needs, read once per tile (a load inside the loop is a full round trip on
+    // the critical path of every batch row, and its s_waitcnt vmcnt(0) also waits for everything else in flight)
+    const size_t img0 = (size_t)a.B * d->g_px_off[g];
+    // Region DMA: which 16-byte chunk a lane fetches for piece k of this wave depends on the tile only, so its
+    // offset (relative to the batch row's first pixel, or to the shared pad row for the live zero pixels t >= L)
+    // and its LDS slot are worked out once per tile; a batch row then costs an add, a select and the load per piece
+    // (generating the addresses in the row loop was ~65 instructions per piece, most of that loop's fixed cost).
+    constexpr int KPMAX = (NS * ((FTN_REGION_PX * 2 + 63) / 64) + 7) / 8;
+    int poff[KPMAX], pdst[KPMAX];
+    unsigned ppad = 0u;
+    const int npc = NS * ppp;
+#pragma unroll
+    for (int k = 0; k < KPMAX; ++k) {
+      const int pc = wv + 8 * k;
+      const int pcc = pc < npc ? pc : 0;
+      const int pz = pcc / ppp, pi = pcc - pz * ppp;
+      int ci = pi * 64 + lane;
+      if (ci >= nchunks16) ci = nchunks16 - 1;
+      const int sp = ci >> 1, half = ci & 1;
+      const int rr = (int)(((float)sp + 0.5f) * inv_rw), cx = sp - rr * RW;
+      const int tpx = (R0 + rr) * p + C0 + cx;
+      const bool pad = btL > 0 && tpx >= btL;
+      poff[k] = (pad ? 0 : tpx * in_groups * PXE) + pz * 16 + half * 8;
+      ppad |= (pad ? 1u : 0u) << k;
+      pdst[k] = __builtin_amdgcn_readfirstlane(pz * plane + pi * 1024);
+    }
+    const __bf16* __restrict__ in_br = a.in + (size_t)(br * a.in_stride_br) * PXE;
+    const __bf16* __restrict__ src_pad = in_br + (size_t)a.B * btL * in_groups * PXE;
+    const size_t row_stride = (size_t)(btL > 0 ? btL : P) * in_groups * PXE;
+    const __bf16* __restrict__ src0 = in_br + (btL > 0 ? (size_t)0 : img0 * in_groups * PXE);
     auto dma_region = [&](int b, int buf) {
-      const __bf16* __restrict__ src = a.in + (btL > 0 ? (size_t)b * btL : (size_t)a.B * d->g_px_off[g] + (size_t)b * P) * in_groups * PXE +
-                                       (size_t)(br * a.in_stride_br) * PXE;
-      const __bf16* __restrict__ src_pad = a.in + (size_t)a.B * btL * in_groups * PXE + (size_t)(br * a.in_stride_br) * PXE;
-      for (int pc = wv; pc < NS * ppp; pc += 8) {
-        const int pz = pc / ppp, pi = pc - pz * ppp;
-        int ci = pi * 64 + lane;
-        if (ci >= nchunks16) ci = nchunks16 - 1;
-        const int sp = ci >> 1, half = ci & 1;
-        const int rr = (int)(((float)sp + 0.5f) * inv_rw), cx = sp - rr * RW;
-        const int tpx = (R0 + rr) * p + C0 + cx;
-        const __bf16* __restrict__ rowp = (btL > 0 && tpx >= btL) ? src_pad : src + (size_t)tpx * in_groups * PXE;
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(rowp + pz * 16 + half * 8),
-            (__attribute__((address_space(3))) void*)(rbuf0 + (size_t)buf * a.region_bytes + (size_t)pz * plane + (size_t)pi * 1024), 16, 0, 0);
+      const __bf16* __restrict__ src = src0 + (size_t)b * row_stride;
+      char* __restrict__ dstb = rbuf0 + (size_t)buf * a.region_bytes;
+#pragma unroll
+      for (int k = 0; k < KPMAX; ++k) {
+        if (wv + 8 * k < npc) {
+          const __bf16* __restrict__ rowp = ((ppad >> k) & 1u) ? src_pad : src;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + poff[k]),
+                                           (__attribute__((address_space(3))) void*)(dstb + pdst[k]), 16, 0, 0);
+        }
       }
     };
     // the tile's first row is requested before the per-lane bookkeeping, so it lands meanwhile (the previous
@@ -1689,6 +1731,7 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
     const int wrot = (wave + b_begin) & 7;
     const int nu = nunits > wrot ? (nunits - wrot + 7) >> 3 : 0;
     int ld[CBF_NU], oidx[CBF_NU];
+    unsigned ooff[CBF_NU];
     unsigned vmask[CBF_NU];
     bool pok[CBF_NU];
 #pragma unroll
@@ -1700,6 +1743,11 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
       const int ri = r0 + r, ci = c0 + c;
       ld[u] = ((ri - R0 - hy) * RW + (ci - C0 - hx)) * CBF_PX_BYTES + (qa & 1) * 16 - zoff;
       oidx[u] = ri * p + ci;
+      {
+        const int ch = br * a.out_stride_br;
+        ooff[u] = a.out_p3 ? (unsigned)((oidx[u] * (a.OUTC >> 4) + (ch >> 4)) * PXE)
+                           : (unsigned)(oidx[u] * a.OUTC + ch + 4 * qa);
+      }
       // taps dy with 0 <= ri + dy - hy < cycles are the bits [lo, hi) of the row mask (same for columns)
       const int rlo = max(0, hy - ri), rhi = min(kh, cycles + hy - ri);
       const int clo = max(0, hx - ci), chi = min(kw, p + hx - ci);
@@ -1716,8 +1764,11 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
       vmask[u] = pok[u] ? m : 0u;
     }
     int it = 0;
+    int keep = 0;                                             // output stores issued behind the newest region DMA
+    const int nst_row = a.dbg != nullptr ? 99 : nu * (a.out_p3 ? 2 : 1);
     for (int b = b_begin; b < b_end; ++b) {
-      __syncthreads();                                        // row b (and, the first time, the weights) have landed
+      barrier_keep_vm(keep);                                  // row b (and, the first time, the weights) have landed
+      keep = __builtin_amdgcn_readfirstlane(nst_row);
       if (b == b_begin) stamp(a.dbg, a.dbg_cap, wgid, 1);
       if (b == b_begin + 1) stamp(a.dbg, a.dbg_cap, wgid, 2);
       if (b + 1 < b_end) dma_region(b + 1, (it + 1) & 1);
@@ -1730,15 +1781,18 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
       if (kw == 7) conv_fast_row<NS, 7, 7>(acc, reg, wlane, ld, vmask, zoff, RW * CBF_PX_BYTES, h1 != 0);
       else if (kw == 5) conv_fast_row<NS, 5, 5>(acc, reg, wlane, ld, vmask, zoff, RW * CBF_PX_BYTES, h1 != 0);
       else conv_fast_row<NS, 3, 3>(acc, reg, wlane, ld, vmask, zoff, RW * CBF_PX_BYTES, h1 != 0);
-      const size_t nimg = (size_t)a.B * d->g_px_off[g] + (size_t)b * P;
+      // uniform row base + per-lane offsets fixed for the tile (ooff)
+      const size_t nimg = img0 + (size_t)b * P;
+      if (a.out_p3) {
+        __bf16* __restrict__ ob = (__bf16*)a.out + nimg * (size_t)(a.OUTC >> 4) * PXE;
 #pragma unroll
-      for (int u = 0; u < CBF_NU; ++u) {
-        if (u < nu && pok[u]) {
-          const int ch = br * a.out_stride_br;
-          const f4 v = NS == 2 ? acc[u] * inv : acc[u];
-          if (a.out_p3) store_px<NS == 2 ? 2 : 3>((__bf16*)a.out + ((nimg + oidx[u]) * (a.OUTC >> 4) + (ch >> 4)) * PXE, qa, v);
-          else *(f4*)((float*)a.out + (nimg + oidx[u]) * a.OUTC + ch + 4 * qa) = v;
-        }
+        for (int u = 0; u < CBF_NU; ++u)
+          if (u < nu && pok[u]) store_px<NS == 2 ? 2 : 3>(ob + ooff[u], qa, NS == 2 ? acc[u] * inv : acc[u]);
+      } else {
+        float* __restrict__ ob = (float*)a.out + nimg * (size_t)a.OUTC;
+#pragma unroll
+        for (int u = 0; u < CBF_NU; ++u)
+          if (u < nu && pok[u]) *(f4*)(ob + ooff[u]) = NS == 2 ? acc[u] * inv : acc[u];
       }
     }
   }
