@@ -332,14 +332,15 @@ def run_rank(args) -> None:
         def pmc_bytes(prefixes):
             tot = 0.0
             for k, v in pmc_k.items():
-                if any(k.startswith(pf) for pf in prefixes) and v.get("hbm_bytes") is not None:
+                if any((k + "(").startswith(pf) for pf in prefixes) and v.get("hbm_bytes") is not None:
                     tot += float(v["hbm_bytes"])
             return tot or None
 
         kname = STAGES[dom].split("(")[-1].rstrip(")")
         traffic = pmc_bytes([kname])
         sel_bytes = 4.0 * B * L * C
-        sel_counter = pmc_bytes(["k_spectrum", "k_colsum", "k_finalize"])
+        # S1-S5 as timed below (standalone selector: plain k_finalize, not the fused finalize + stage-A launch)
+        sel_counter = pmc_bytes(["k_spectrum", "k_colsum", "k_finalize("])
         out = {
             "metric": "TimesBlock-forward series/sec (B=256 L=336 N=512)",
             "value": value, "unit": "series/s", "n_gpus": dist_world if use_dist else 1, "steps": args.steps,
@@ -368,6 +369,8 @@ def run_rank(args) -> None:
                          "frac_algorithmic": achieved / peak_tf, "frac_pipe": frac_pipe,
                          "flops_per_launch": flops_alg, "avg_launch_ms": stage_ms[dom],
                          "stage_ms": dict(zip(STAGES, [round(v, 4) for v in stage_ms])),
+                         "stage_note": "stage A (a = W_in1 x + b) runs inside the selector's finalize launch "
+                                       "(k_finalize_pw), so A_pw_in only brackets two event marks",
                          "conv_path_ms": conv_ms,
                          "block_executed_tflops": executed / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                          "block_nominal_tflops": nominal / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
