@@ -213,16 +213,18 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) { pw_body<ACT, XIN, XVEC, 
 // sanitised descriptor copy at the head of the workspace), workgroups 1.. are stage A - so stage A's ~22 us
 // disappear behind the selector's tail (ftn_period_finalize_stage_a).
 #include "ftn_finalize.h"
+// part: 0 = both (workgroup 0 finalizes, the others run stage A), 1 = stage A only (a sharded batch runs it while
+// the partial sums are exchanged), 2 = finalize + descriptor copy only (one workgroup, after that exchange)
 template <int ACT, bool XVEC, int EPI>
-__global__ __launch_bounds__(256) void k_finalize_pw(FinalizeArgs fa, PwArgs pa) {
-  if (blockIdx.x == 0) {
+__global__ __launch_bounds__(256) void k_finalize_pw(FinalizeArgs fa, PwArgs pa, int part) {
+  if (part != 1 && blockIdx.x == 0) {
     finalize_body(fa);
     __syncthreads();
     guard_desc(fa.desc, pa.guard_dst, pa.guard_groups, pa.guard_px);
-  } else {
+  } else if (part != 2) {
     PwArgs q = pa;
     q.guard_dst = nullptr;
-    pw_body<ACT, 1, XVEC, EPI>(q, (int)blockIdx.x - 1);
+    pw_body<ACT, 1, XVEC, EPI>(q, (int)blockIdx.x - (part == 0 ? 1 : 0));
   }
 }
 
@@ -2155,12 +2157,15 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
 static struct StageProf {
   bool on = false;
   bool created = false;
-  int calls = 0;
+  int calls = 0;        // forwards recorded
+  int every = 1;        // record every `every`-th forward
+  int seen = 0;         // forwards seen since ftn_stage_timing(enable)
   hipEvent_t ev[FTN_PROF_CALLS][FTN_NSTAGE + 1];
+  bool sampling() const { return on && calls < FTN_PROF_CALLS && seen % every == 0; }
 } g_prof;
 
 static void prof_mark(int stage, hipStream_t st) {
-  if (g_prof.on && g_prof.calls < FTN_PROF_CALLS) (void)hipEventRecord(g_prof.ev[g_prof.calls][stage], st);
+  if (g_prof.sampling()) (void)hipEventRecord(g_prof.ev[g_prof.calls][stage], st);
 }
 
 extern "C" int ftn_debug_stamps(void* buf_dev, size_t n_u64, int which) {
@@ -2180,7 +2185,9 @@ extern "C" int ftn_stage_timing(int enable) {
     g_prof.created = true;
   }
   g_prof.on = enable != 0;
+  g_prof.every = enable > 1 ? enable : 1;
   g_prof.calls = 0;
+  g_prof.seen = 0;
   return 0;
 }
 
@@ -2736,7 +2743,10 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     FTN_CHECK_LAUNCH();
   }
   prof_mark(6, st);
-  if (g_prof.on && g_prof.calls < FTN_PROF_CALLS) ++g_prof.calls;
+  if (g_prof.on) {
+    if (g_prof.sampling()) ++g_prof.calls;
+    ++g_prof.seen;
+  }
   return 0;
 }
 
@@ -2774,16 +2784,16 @@ static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const
 // S3-S5 of the selector and stage A of the block in ONE launch (k_finalize_pw): see flowtimes.h
 template <int ACT>
 static int finalize_stage_a_t(const FinalizeArgs& fa, const PwArgs& pa, int epi, bool xvec, int nblk_pw, size_t lds,
-                              hipStream_t st) {
-  const dim3 grid(1 + nblk_pw), blk(256);
+                              int part, hipStream_t st) {
+  const dim3 grid(part == 0 ? 1 + nblk_pw : (part == 1 ? nblk_pw : 1)), blk(256);
   if (xvec) {
-    if (epi == 3) hipLaunchKernelGGL((k_finalize_pw<ACT, true, 3>), grid, blk, lds, st, fa, pa);
-    else if (epi == 2) hipLaunchKernelGGL((k_finalize_pw<ACT, true, 2>), grid, blk, lds, st, fa, pa);
-    else hipLaunchKernelGGL((k_finalize_pw<ACT, true, 0>), grid, blk, lds, st, fa, pa);
+    if (epi == 3) hipLaunchKernelGGL((k_finalize_pw<ACT, true, 3>), grid, blk, lds, st, fa, pa, part);
+    else if (epi == 2) hipLaunchKernelGGL((k_finalize_pw<ACT, true, 2>), grid, blk, lds, st, fa, pa, part);
+    else hipLaunchKernelGGL((k_finalize_pw<ACT, true, 0>), grid, blk, lds, st, fa, pa, part);
   } else {
-    if (epi == 3) hipLaunchKernelGGL((k_finalize_pw<ACT, false, 3>), grid, blk, lds, st, fa, pa);
-    else if (epi == 2) hipLaunchKernelGGL((k_finalize_pw<ACT, false, 2>), grid, blk, lds, st, fa, pa);
-    else hipLaunchKernelGGL((k_finalize_pw<ACT, false, 0>), grid, blk, lds, st, fa, pa);
+    if (epi == 3) hipLaunchKernelGGL((k_finalize_pw<ACT, false, 3>), grid, blk, lds, st, fa, pa, part);
+    else if (epi == 2) hipLaunchKernelGGL((k_finalize_pw<ACT, false, 2>), grid, blk, lds, st, fa, pa, part);
+    else hipLaunchKernelGGL((k_finalize_pw<ACT, false, 0>), grid, blk, lds, st, fa, pa, part);
   }
   FTN_CHECK_LAUNCH();
   return 0;
@@ -2795,10 +2805,16 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
                                            float* weights_dev, const float* x_dev, const FtnPlan* plan,
                                            const float* wblob_dev, int max_groups, int px_bound, void* ws_dev,
                                            size_t ws_bytes, void* stream) {
-  FTN_CHECK_ARG(psum_dev && med_dev && desc_dev && amps_dev && weights_dev && x_dev && plan && wblob_dev && ws_dev,
-                "ftn_period_finalize_stage_a: null pointer");
-  FTN_CHECK_ARG(B >= 1 && B <= 65535 && L >= 2 && nparts >= 1 && Btotal >= B, "ftn_period_finalize_stage_a: bad shape");
-  FTN_CHECK_ARG((((uintptr_t)amps_dev | (uintptr_t)weights_dev) & 15) == 0, "ftn_period_finalize_stage_a: amps / weights must be 16-byte aligned");
+  // psum_dev == NULL: stage A only;  x_dev == NULL: finalize + descriptor copy only (stage A is in the workspace)
+  const bool do_fin = psum_dev != nullptr, do_a = x_dev != nullptr;
+  FTN_CHECK_ARG(do_fin || do_a, "ftn_period_finalize_stage_a: nothing to do (psum and x both null)");
+  FTN_CHECK_ARG(plan && wblob_dev && ws_dev, "ftn_period_finalize_stage_a: null pointer");
+  if (do_fin) {
+    FTN_CHECK_ARG(med_dev && desc_dev && amps_dev && weights_dev, "ftn_period_finalize_stage_a: null pointer");
+    FTN_CHECK_ARG((((uintptr_t)amps_dev | (uintptr_t)weights_dev) & 15) == 0, "ftn_period_finalize_stage_a: amps / weights must be 16-byte aligned");
+    FTN_CHECK_ARG(nparts >= 1 && Btotal >= B, "ftn_period_finalize_stage_a: bad shape");
+  }
+  FTN_CHECK_ARG(B >= 1 && B <= 65535 && L >= 2, "ftn_period_finalize_stage_a: bad shape");
   FTN_CHECK_ARG(k_periods <= FTN_KMAX && act_dtype >= 0 && act_dtype <= 2, "ftn_period_finalize_stage_a: k=%d act_dtype=%d", k_periods, act_dtype);
   FTN_CHECK_ARG(plan->mode == 0 && plan->MP > 0 && plan->MP % 16 == 0, "ftn_period_finalize_stage_a: bottleneck blocks only");
   FTN_CHECK_ARG(max_groups >= 1 && max_groups <= FTN_KMAX && px_bound >= 0, "ftn_period_finalize_stage_a: bounds");
@@ -2828,8 +2844,9 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
   pa.guard_px = worst_px_per_row(L, max_groups, px_bound);
   const bool xvec = (plan->C % 4 == 0) && (((uintptr_t)x_dev & 15) == 0);
   const int nblk_pw = (int)(((long long)B * L + 1 + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));
-  if (plan->act == 1) return finalize_stage_a_t<1>(fa, pa, epi, xvec, nblk_pw, lds, (hipStream_t)stream);
-  return finalize_stage_a_t<0>(fa, pa, epi, xvec, nblk_pw, lds, (hipStream_t)stream);
+  const int part = do_fin && do_a ? 0 : (do_a ? 1 : 2);
+  if (plan->act == 1) return finalize_stage_a_t<1>(fa, pa, epi, xvec, nblk_pw, lds, part, (hipStream_t)stream);
+  return finalize_stage_a_t<0>(fa, pa, epi, xvec, nblk_pw, lds, part, (hipStream_t)stream);
 }
 
 extern "C" int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,

@@ -135,20 +135,28 @@ class FFTPeriodSelector(nn.Module):
         xf = xf.contiguous()
         med, psum = runtime.spectrum(xf)
         b_total = B
+        pre = None
         if self.shard_group is not None:
             import torch.distributed as dist
 
             world = dist.get_world_size(self.shard_group)
             parts = torch.empty(world, psum.numel(), dtype=psum.dtype, device=psum.device)
+            # the block's stage A needs x only: it runs while the partial sums travel
+            overlap = stage_a is not None and runtime.fuse_stage_a(stage_a[0])
             if dist.get_backend(self.shard_group) == "gloo":      # CPU-side rehearsal of the exchange
+                if overlap:
+                    pre = runtime.stage_a_only(xf, stage_a[0], stage_a[1], self.k, self.pmax, self.min_period_threshold)
                 dist.all_gather(list(parts.unbind(0)), psum, group=self.shard_group)
             else:                                                  # RCCL
-                dist.all_gather_into_tensor(parts, psum, group=self.shard_group)
+                work = dist.all_gather_into_tensor(parts, psum, group=self.shard_group, async_op=True)
+                if overlap:                                        # enqueued behind the spectrum, beside the exchange
+                    pre = runtime.stage_a_only(xf, stage_a[0], stage_a[1], self.k, self.pmax, self.min_period_threshold)
+                work.wait()                                        # the compute stream waits; the host does not
             b_total = B * world          # equal shards (no host sync to learn otherwise)
             psum = parts
         sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold, adt,
                                max_unique or 0, log_base or 0.0,
-                               stage_a=None if stage_a is None else (xf, stage_a[0], stage_a[1]))
+                               stage_a=None if stage_a is None else (xf, stage_a[0], stage_a[1]), pre=pre)
         self._pending = sel
         return sel
 

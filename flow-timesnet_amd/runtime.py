@@ -104,16 +104,47 @@ def spectrum(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 ACT_DTYPE = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
 
 
+def _selector_bounds(lib, L: int, k: int, pmax: int, min_thr: int) -> Tuple[int, int]:
+    mg = C.c_int(0)
+    pxb = lib.ftn_selector_px_bound(L, int(k), int(pmax), int(min_thr), C.byref(mg))
+    if pxb < 0:
+        check(pxb, "ftn_selector_px_bound")
+    return max(1, int(mg.value)), int(pxb)
+
+
+def fuse_stage_a(plan) -> bool:
+    """Stage A can ride with the selector's finalize launch (bottleneck blocks; FTN_FUSE_STAGE_A=0 disables)."""
+    return plan.mode == 0 and os.getenv("FTN_FUSE_STAGE_A", "1") != "0"
+
+
+def stage_a_only(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, k: int, pmax: int, min_thr: int):
+    """Stage A of the block into a fresh workspace, without the selection (``ftn_period_finalize_stage_a`` with
+    ``psum = NULL``): a batch-sharded run launches it between issuing the exchange of the partial sums and waiting
+    for it.  Returns the token ``finalize(..., stage_a=..., pre=token)`` completes."""
+    lib = _lib.load()
+    B, L, _ = x.shape
+    mg, pxb = _selector_bounds(lib, L, k, pmax, min_thr)
+    need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, mg, pxb)
+    if need == 0:
+        raise ValueError(f"ftn_timesblock_workspace_bytes rejected the shape (B={B}, L={L})")
+    ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+    check(lib.ftn_period_finalize_stage_a(None, 0, 0, None, B, L, int(k), int(pmax), int(min_thr), 0, 0, 0.0,
+                                          None, None, None, _ptr(x), C.byref(plan), _ptr(wblob), mg, pxb, _ptr(ws),
+                                          ws.numel(), _stream(x.device)), "ftn_period_finalize_stage_a")
+    return ws
+
+
 def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int, pmax: int,
              min_thr: int, act_dtype: int = 0, max_unique: int = 0, log_base: float = 0.0,
-             stage_a=None) -> Selection:
+             stage_a=None, pre=None) -> Selection:
     """S3-S5 on the device.  ``psum`` is [F] or [nparts, F] (multi-GPU partial sums); ``act_dtype`` 1 / 2
     applies the reference's bf16 / fp16 roundings of scores, amplitudes and weights.
 
     ``stage_a=(x, plan, wblob)``: the block that consumes this selection is known, so its stage A
     (a = W_in1 x + b, independent of the selection) rides in the same launch
     (``ftn_period_finalize_stage_a``); the returned Selection then owns the block's workspace and
-    ``timesblock_forward`` skips stage A."""
+    ``timesblock_forward`` skips stage A.  ``pre`` = the workspace ``stage_a_only`` already filled: only S3-S5 and
+    the descriptor copy remain."""
     lib = _lib.load()
     B = med.shape[0]
     dev = med.device
@@ -121,20 +152,21 @@ def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int
     desc = torch.empty(DESC_INTS, dtype=torch.int32, device=dev)
     amps = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
     wts = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
-    mg = C.c_int(0)
-    pxb = lib.ftn_selector_px_bound(L, int(k), int(pmax), int(min_thr), C.byref(mg))
-    if pxb < 0:
-        check(pxb, "ftn_selector_px_bound")
-    sel = Selection(desc, amps, wts, max(1, int(mg.value)), int(pxb))
-    if stage_a is not None and stage_a[1].mode == 0 and os.getenv("FTN_FUSE_STAGE_A", "1") != "0":
+    mg, pxb = _selector_bounds(lib, L, k, pmax, min_thr)
+    sel = Selection(desc, amps, wts, mg, pxb)
+    if stage_a is not None and (pre is not None or fuse_stage_a(stage_a[1])):
         x, plan, wblob = stage_a
-        need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, sel.max_groups, sel.px_bound)
-        if need == 0:
-            raise ValueError(f"ftn_timesblock_workspace_bytes rejected the shape (B={B}, L={L})")
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        if pre is None:
+            need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, sel.max_groups, sel.px_bound)
+            if need == 0:
+                raise ValueError(f"ftn_timesblock_workspace_bytes rejected the shape (B={B}, L={L})")
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        else:
+            ws = pre
         check(lib.ftn_period_finalize_stage_a(_ptr(psum), nparts, int(b_total), _ptr(med), B, L, int(k), int(pmax),
                                               int(min_thr), int(act_dtype), int(max_unique or 0),
-                                              float(log_base or 0.0), _ptr(desc), _ptr(amps), _ptr(wts), _ptr(x),
+                                              float(log_base or 0.0), _ptr(desc), _ptr(amps), _ptr(wts),
+                                              _ptr(x) if pre is None else None,
                                               C.byref(plan), _ptr(wblob), sel.max_groups, sel.px_bound, _ptr(ws),
                                               ws.numel(), _stream(dev)),
               "ftn_period_finalize_stage_a")

@@ -196,7 +196,10 @@ int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const
  * selector) in ONE launch: workgroup 0 is the finalize kernel and then publishes the sanitised descriptor copy at
  * the head of the workspace, the other workgroups compute stage A - the selector's single-workgroup tail (~17 us)
  * no longer leaves the chip idle.  Same plan / workspace / bounds as the ftn_timesblock_forward call that
- * follows with FTN_FWD_STAGE_A_DONE.  Bottleneck-mode plans only (mode 0). */
+ * follows with FTN_FWD_STAGE_A_DONE.  Bottleneck-mode plans only (mode 0).
+ * The two halves can also be launched apart, on the same workspace - a batch-sharded run puts stage A between
+ * issuing the exchange of the partial sums and waiting for it:  psum_dev == NULL runs stage A only (med / desc /
+ * amps / weights unused),  x_dev == NULL runs S3-S5 and the descriptor copy only. */
 int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B, int L,
                                 int k_periods, int pmax, int min_period_threshold, int act_dtype, int max_unique,
                                 float log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
@@ -254,8 +257,10 @@ int ftn_embed_forward(const float* x_dev, long long x_bstride, int B, int L, int
 
 /* ---- measurement ---------------------------------------------------------------- */
 /* hipEvent brackets around the 6 stages (A pw-in, B conv, C fused pointwise chain,
- * D conv, E pw-out, F combine) of every following ftn_timesblock_forward call (up to
- * 512 calls); nothing synchronises until ftn_stage_times is called. */
+ * D conv, E pw-out, F combine) of the following ftn_timesblock_forward calls - every
+ * `enable`-th call (1 = every call, 0 = off; the events themselves cost ~3 us each on the
+ * stream), up to 512 recorded calls; nothing synchronises until ftn_stage_times is called.
+ * The first enabling call creates the events (host time): do it outside a timed region. */
 int ftn_stage_timing(int enable);
 /* sums, over the calls recorded since ftn_stage_timing(1), of each stage's elapsed
  * milliseconds; synchronises on the recorded events.  nstage must be 6. */

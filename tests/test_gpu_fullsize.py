@@ -282,6 +282,17 @@ def test_fused_finalize_stage_a_equals_two_launches(B, L, C, engine, ftn, dev, m
         assert torch.equal(a, b)
     assert torch.equal(outs[0][3], outs[0][4])
     assert not torch.equal(outs[0][3], x.cpu())
+    # the two halves launched apart (what a batch-sharded run does around the exchange of the partial sums)
+    monkeypatch.setenv("FTN_FUSE_STAGE_A", "1")
+    wblob, plan = blk._packed(dev)
+    sm = blk.period_selector
+    med, psum = rt.spectrum(x)
+    pre = rt.stage_a_only(x, plan, wblob, sm.k, sm.pmax, sm.min_period_threshold)
+    sel = rt.finalize(psum, B, med, L, sm.k, sm.pmax, sm.min_period_threshold, stage_a=(x, plan, wblob), pre=pre)
+    assert sel.stage_a is not None
+    y = rt.timesblock_forward(x, plan, wblob, sel)
+    for a, b in zip((sel.desc.cpu(), sel.amps.cpu(), sel.weights.cpu(), y.cpu()), outs[0][:4]):
+        assert torch.equal(a, b)
 
 
 def test_fused_stage_a_rejects_a_foreign_input(ftn, dev):
