@@ -216,12 +216,10 @@ def run_rank(args) -> None:
         pkg.lib.check(lib.ftn_stage_timing(1), "ftn_stage_timing")      # creates the events
         lib.ftn_stage_timing(0)
         # bring the clocks up before the W warm-up steps the caller asked for (a W of 2-5 steps is 1-3 ms: the
-        # same K steps then time 10-25 % slower than behind a 50 ms run-in - measured, round 2)
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.1:
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
+        # same K steps then time 10-25 % slower than behind a 0.1 s run-in - measured, round 2)
+        for _ in range(200):       # a fixed count, not a time: every rank must issue the same number of exchanges
+            step()
+        torch.cuda.synchronize()
         for _ in range(args.warmup):
             y = step()
         drain()
