@@ -1525,7 +1525,13 @@ __device__ __forceinline__ void barrier_keep_vm(int keep) {
   }
 }
 
-#define CBF_FAST_PLANE (FTN_REGION_PX * CBF_PX_BYTES + 64)
+// A plane = the region's pixels + a 256-byte block of zeros (one 16-byte slot per LDS bank quad) that taps outside
+// the grid are redirected to.  A redirected lane reads the slot of ITS OWN would-be address ((addr & 0xF0) in the
+// block), so it keeps the bank quad it would have used and a ds_read_b128 lane group stays conflict-free; with one
+// shared zero pixel every mixed group paid a 2-way conflict (PMC: 17 % of this kernel's LDS cycles, and LDS time
+// is level with MFMA time here).
+#define CBF_FAST_ZBASE (FTN_REGION_PX * CBF_PX_BYTES)
+#define CBF_FAST_PLANE (CBF_FAST_ZBASE + 256)
 
 template <int NS, int KH, int KW>
 __device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __restrict__ reg, const char* __restrict__ wlane,
@@ -1554,8 +1560,9 @@ __device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __r
     }
 #pragma unroll
     for (int u = 0; u < CBF_NU; ++u) {
-      const int v = (int)__builtin_amdgcn_ubfe(vmask[u], (unsigned)s, 1u);
-      const int addr = __mul24(v, ld[u] + toff) + zoffv;          // valid ? pixel + tap : zero pixel
+      const int t = ld[u] + toff;
+      const bool v = ((vmask[u] >> s) & 1u) != 0u;
+      const int addr = v ? t : ((t & 0xF0) | CBF_FAST_ZBASE);     // valid ? pixel + tap : its slot of the zero block
 #pragma unroll
       for (int pz = 0; pz < NS; ++pz) bp[u][pz] = *(const bf8*)(reg + addr + pz * CBF_FAST_PLANE);
     }
@@ -1638,10 +1645,11 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) { a.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime(); a.dbg[wgid * 8 + 4] = (unsigned long long)ntaps; a.dbg[wgid * 8 + 5] = 0; }
   char* __restrict__ wl = ldsb;
   char* __restrict__ rbuf0 = ldsb + (size_t)S * 3 * 1024;      // behind THIS branch's weight fragments
-  const int zoff = plane - 64 + (qa & 1) * 16;               // zero pixel at the end of every plane
-  if (threadIdx.x < 2 * NS * 4) {                            // zero pixels of both region buffers
-    const int pl = threadIdx.x >> 2;
-    *(f4*)(rbuf0 + (size_t)(pl / NS) * a.region_bytes + (size_t)(pl % NS) * plane + plane - 64 + (threadIdx.x & 3) * 16) = f4{0.f, 0.f, 0.f, 0.f};
+  const int zoff = 0;                                        // (kept for conv_fast_row's signature)
+  static_assert(CBF_FAST_ZBASE % 256 == 0, "the zero block must start on a 256-byte boundary");
+  if (threadIdx.x < 2 * NS * 16) {                           // zero blocks of both region buffers
+    const int pl = threadIdx.x >> 4;
+    *(f4*)(rbuf0 + (size_t)(pl / NS) * a.region_bytes + (size_t)(pl % NS) * plane + CBF_FAST_ZBASE + (threadIdx.x & 15) * 16) = f4{0.f, 0.f, 0.f, 0.f};
   }
   {                                                            // every slab of the branch's one output tile, once
     const __bf16* __restrict__ src = a.W[br];
@@ -1743,7 +1751,7 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
       if (!pok[u]) idx = 0;
       const int r = (int)(((float)idx + 0.5f) * inv_tw), c = idx - r * tw;
       const int ri = r0 + r, ci = c0 + c;
-      ld[u] = ((ri - R0 - hy) * RW + (ci - C0 - hx)) * CBF_PX_BYTES + (qa & 1) * 16 - zoff;
+      ld[u] = ((ri - R0 - hy) * RW + (ci - C0 - hx)) * CBF_PX_BYTES + (qa & 1) * 16;
       oidx[u] = ri * p + ci;
       {
         const int ch = br * a.out_stride_br;
