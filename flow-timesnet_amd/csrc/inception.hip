@@ -1292,13 +1292,13 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
   char* __restrict__ wl = ldsb;
   char* __restrict__ rbuf0 = ldsb + a.wbytes;
   const int plane = a.plane_bytes;
-  const int zoff = plane - 64 + (qa & 1) * 16;               // zero pixel at the end of every plane
+  const int zbase = plane - 256;                             // 256-byte zero block at the end of every plane (256-aligned)
   const int b_begin = blockIdx.y * a.bpw, b_end = min(a.B, b_begin + a.bpw);
   const int G = d->n_groups, tiles_total = d->tiles_per_row;
-  // zero pixels of every plane of both region buffers (never overwritten by the DMA)
-  if (threadIdx.x < 2 * NS * 4) {
-    const int pl = threadIdx.x >> 2;                           // (buffer, piece) plane index
-    *(f4*)(rbuf0 + (size_t)(pl / NS) * a.region_bytes + (size_t)(pl % NS) * plane + plane - 64 + (threadIdx.x & 3) * 16) = f4{0.f, 0.f, 0.f, 0.f};
+  // zero blocks of every plane of both region buffers (never overwritten by the DMA)
+  if (threadIdx.x < 2 * NS * 16) {
+    const int pl = threadIdx.x >> 4;                           // (buffer, piece) plane index
+    *(f4*)(rbuf0 + (size_t)(pl / NS) * a.region_bytes + (size_t)(pl % NS) * plane + zbase + (threadIdx.x & 15) * 16) = f4{0.f, 0.f, 0.f, 0.f};
   }
   const size_t wgid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   stamp(a.dbg, a.dbg_cap, wgid, 0);
@@ -1424,7 +1424,8 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
 #pragma unroll
           for (int u = 0; u < CBF_NU; ++u) {
             const bool v = tapok && (((rmask[u] >> dy) & (cmask[u] >> dx) & 1u) != 0u);
-            const char* __restrict__ src = reg + (v ? lbase[u] + toff : zoff);
+            const int t = lbase[u] + toff;
+            const char* __restrict__ src = reg + (v ? t : ((t & 0xF0) | zbase));   // its own slot of the zero block: no bank conflict
 #pragma unroll
             for (int pz = 0; pz < NS; ++pz) bp[u][pz] = *(const bf8*)(src + (size_t)pz * plane);
           }
@@ -1535,7 +1536,7 @@ __device__ __forceinline__ void barrier_keep_vm(int keep) {
 
 template <int NS, int KH, int KW>
 __device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __restrict__ reg, const char* __restrict__ wlane,
-                                               const int (&ld)[CBF_NU], const unsigned (&vmask)[CBF_NU], int zoffv,
+                                               const int (&ld)[CBF_NU], const unsigned (&vmask)[CBF_NU],
                                                int RW32, bool half1) {
   constexpr int NWP = PxFmt<NS>::NW;
   constexpr int NT = KH * KW, S = (NT + 1) / 2;
@@ -1645,7 +1646,6 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) { a.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime(); a.dbg[wgid * 8 + 4] = (unsigned long long)ntaps; a.dbg[wgid * 8 + 5] = 0; }
   char* __restrict__ wl = ldsb;
   char* __restrict__ rbuf0 = ldsb + (size_t)S * 3 * 1024;      // behind THIS branch's weight fragments
-  const int zoff = 0;                                        // (kept for conv_fast_row's signature)
   static_assert(CBF_FAST_ZBASE % 256 == 0, "the zero block must start on a 256-byte boundary");
   if (threadIdx.x < 2 * NS * 16) {                           // zero blocks of both region buffers
     const int pl = threadIdx.x >> 4;
@@ -1788,9 +1788,9 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
       const char* __restrict__ reg = rbuf0 + (size_t)(it & 1) * a.region_bytes;
       ++it;
       const char* __restrict__ wlane = wl + lane * 16;
-      if (kw == 7) conv_fast_row<NS, 7, 7>(acc, reg, wlane, ld, vmask, zoff, RW * CBF_PX_BYTES, h1 != 0);
-      else if (kw == 5) conv_fast_row<NS, 5, 5>(acc, reg, wlane, ld, vmask, zoff, RW * CBF_PX_BYTES, h1 != 0);
-      else conv_fast_row<NS, 3, 3>(acc, reg, wlane, ld, vmask, zoff, RW * CBF_PX_BYTES, h1 != 0);
+      if (kw == 7) conv_fast_row<NS, 7, 7>(acc, reg, wlane, ld, vmask, RW * CBF_PX_BYTES, h1 != 0);
+      else if (kw == 5) conv_fast_row<NS, 5, 5>(acc, reg, wlane, ld, vmask, RW * CBF_PX_BYTES, h1 != 0);
+      else conv_fast_row<NS, 3, 3>(acc, reg, wlane, ld, vmask, RW * CBF_PX_BYTES, h1 != 0);
       // uniform row base + per-lane offsets fixed for the tile (ooff)
       const size_t nimg = img0 + (size_t)b * P;
       if (a.out_p3) {
@@ -2367,7 +2367,7 @@ static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int
     int sl = (kh[k] * kw[k] + 1) / 2;
     if (sl > smax) smax = sl;
   }
-  gm.plane_bytes = ((region_px * CBF_PX_BYTES + 1023) & ~1023) + 64;     // whole DMA pieces + the zero pixel
+  gm.plane_bytes = ((region_px * CBF_PX_BYTES + 1023) & ~1023) + 256;    // whole DMA pieces + the zero block (see CBF_FAST_ZBASE)
   gm.region_bytes = npieces * gm.plane_bytes;
   const int nco_tot = cout / 16;
   if (sq357 && region_px <= FTN_REGION_PX && !g_conv_generic) {
