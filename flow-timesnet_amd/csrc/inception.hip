@@ -104,6 +104,39 @@ __device__ __forceinline__ Px decode_px(const FtnDesc* __restrict__ d, const flo
   return p;
 }
 
+// The same for the 16 CONSECUTIVE pixels n0 + j of one MFMA pixel unit (n0 wave-uniform).  They almost always lie
+// in one period group, which a scalar walk over the (at most 16) prefix sums finds: the per-lane part is then a
+// division by a uniform P.  decode_px's per-lane 16-way select chain is ~150 VALU + SALU instructions, a tenth of
+// what a stage-C wave executes for its unit.  Units that straddle a group boundary take the general path.
+__device__ __forceinline__ Px decode_px16(const FtnDesc* __restrict__ d, const float* __restrict__ x, int B, int L,
+                                          int C, int n0, int j, int N) {
+  const int G = d->n_groups;
+  const int first = __builtin_amdgcn_readfirstlane(n0);
+  const int last = first + 15 < N ? first + 15 : N - 1;
+  int off[FTN_KMAX + 1];                                          // one batch of scalar loads, then SALU selects
+#pragma unroll
+  for (int i = 0; i <= FTN_KMAX; ++i) off[i] = d->g_px_off[i];
+  int lo = 0, hi = off[1];
+#pragma unroll
+  for (int gg = 1; gg < FTN_KMAX; ++gg) {
+    const bool in = gg < G && first >= B * off[gg];
+    lo = in ? off[gg] : lo;
+    hi = in ? off[gg + 1] : hi;
+  }
+  if (first < N && last < B * hi) {                              // whole unit inside one group (uniform branch)
+    Px p;
+    const int n = first + j;
+    p.ok = n < N;
+    p.n = p.ok ? n : N - 1;
+    const int P = hi - lo;
+    const int rem = p.n - B * lo;
+    const int b = rem / P, t = rem - b * P;
+    p.xrow = (t < L) ? x + ((size_t)b * L + t) * C : nullptr;
+    return p;
+  }
+  return decode_px(d, x, B, L, C, n0 + j, N);
+}
+
 template <bool XVEC>
 __device__ __forceinline__ f4 load_x4(const float* __restrict__ xrow, int c, int C) {
   f4 v = {0.f, 0.f, 0.f, 0.f};
@@ -148,7 +181,7 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bid) {
       px[u].n = px[u].ok ? n : N - 1;
       px[u].xrow = px[u].n < N - 1 ? a.x + (size_t)px[u].n * a.C : nullptr;
     } else {
-      px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
+      px[u] = decode_px16(d, a.x, a.B, a.L, a.C, n0 + 16 * u, j, N);
     }
   }
   const int KIN = a.KIN;
@@ -312,7 +345,7 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
   dma_chunk(0, 0);                                               // lands while the pixels are decoded
   Px px[NPX];
 #pragma unroll
-  for (int u = 0; u < NPX; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
+  for (int u = 0; u < NPX; ++u) px[u] = decode_px16(d, a.x, a.B, a.L, a.C, n0 + 16 * u, j, N);
   const int FP = a.FP, KM = a.KM, CP = a.CP;
   const int nht = FP >> 4;
   const int nKM = a.nKM, nCP = a.nCP, n_ot = EXACT ? OTM : a.n_ot;
@@ -620,7 +653,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
   // the chunk-0 weight DMA and the bias staging, which are not needed before the first barrier.
   Px px[NPX];
 #pragma unroll
-  for (int u = 0; u < NPX; ++u) px[u] = decode_px(d, a.x, a.B, a.L, a.C, n0 + 16 * u + j, N);
+  for (int u = 0; u < NPX; ++u) px[u] = decode_px16(d, a.x, a.B, a.L, a.C, n0 + 16 * u, j, N);
   const int CP = a.CP;
   const int nsKM = a.nsKM, nsCP = a.nsCP, n_ot = EXACT ? OTM : a.n_ot;
   const int kmg = a.KM >> 4;                                  // 16-channel groups of m
@@ -857,7 +890,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
                                        (__attribute__((address_space(3))) void*)(dst + (size_t)piece * 1024), 16, 0, 0);
   };
-  const Px px = decode_px(d, a.x, a.B, a.L, a.C, n0 + j, N);
+  const Px px = decode_px16(d, a.x, a.B, a.L, a.C, n0, j, N);
   const int CP = a.CP;
   const int kmg = a.KM >> 4;
   constexpr int NWP = PxFmt<NS>::NW;
