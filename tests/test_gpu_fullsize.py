@@ -63,6 +63,25 @@ def test_c1_full_size_fp32_engine(ftn, dev):
     _full_size_block_properties(ftn, dev, 256, 336, 64, 3, "f32", [24, 168, 7], [0, 17, 128, 255])
 
 
+@pytest.mark.parametrize("engine", ["f16x2", "bf16x3"])
+def test_c2_full_size_split_engines(engine, ftn, dev):
+    """BASELINE configs[2] = the bench shape: B=256 L=336 d_model=64 k=5 on the split engines.  At this size every
+    conv workgroup walks several batch rows of a tile (the counted-vmcnt row barrier and the double-buffered region
+    DMA of k_conv_bf_fast), the selector takes its row-resident quarter-fold form and stage A rides in the finalize
+    launch - none of which the small fixtures reach.  Also checked against the exact fp32-MFMA engine on EVERY row."""
+    _full_size_block_properties(ftn, dev, 256, 336, 64, 5, engine, [24, 168, 7, 12, 84], [0, 17, 128, 255])
+    case = dict(hyper="pipeline", C=64, seed=0)
+    x = torch.from_numpy(ftn.synth.make_input(256, 336, 64, seed=0)).to(dev)
+    ys = []
+    for eng in (engine, "f32"):
+        blk, _, _, _ = _block(ftn, case, dev, eng)
+        blk.period_selector = ftn.models.timesnet.FFTPeriodSelector(5, 336)
+        with torch.inference_mode():
+            ys.append(blk(x))
+        assert blk._last_backend == "hip"
+    np.testing.assert_allclose(ys[0].cpu().numpy(), ys[1].cpu().numpy(), rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("engine", ["f16x2", "bf16x3", "f32"])
 def test_c3_full_size_block(engine, ftn, dev):
     """BASELINE configs[3] (one GPU's TimesBlock): B=256 L=720 d_model=128 d_ff=512 k=5 - 0.95 M grid pixels,
