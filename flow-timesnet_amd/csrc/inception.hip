@@ -37,6 +37,7 @@ static unsigned long long* g_stamp_buf = nullptr;
 static size_t g_stamp_cap = 0;
 static int g_stamp_which = 0;  // 1: k_conv, 2: k_mlp
 static const bool g_conv_generic = [] { const char* e = getenv("FTN_CONV_GENERIC"); return e != nullptr && e[0] == '1'; }();  // experiment switch
+static const bool g_mlp_split = [] { const char* e = getenv("FTN_MLP_SPLIT"); return e == nullptr || e[0] != '0'; }();   // split refill (default on)
 static const bool g_mlp_pfd2 = [] { const char* e = getenv("FTN_MLP_PFD"); return e != nullptr && e[0] == '2'; }();   // experiment: fragment reads two steps ahead
 static const bool g_mlp_w16 = [] { const char* e = getenv("FTN_MLP_W16"); return e != nullptr && e[0] == '1'; }();   // experiment: 16-wave double-buffered k_mlp_bf_u1
 static const bool g_mlp_w4 = [] { const char* e = getenv("FTN_MLP_W4"); return e != nullptr && e[0] == '1'; }();     // experiment: 4-wave workgroups, three per CU
@@ -69,6 +70,23 @@ __device__ __forceinline__ void guard_desc(const FtnDesc* __restrict__ src, FtnD
   const bool bad = src->n_groups < 0 || src->n_groups > max_groups || src->total_px < 0 || src->total_px > px_bound;
   for (int e = threadIdx.x; e < (int)(sizeof(FtnDesc) / 4); e += blockDim.x) d[e] = bad ? 0 : s[e];
   if (threadIdx.x == 0) d[sizeof(FtnDesc) / 4] = bad ? 1 : 0;
+}
+
+// Workgroup barrier that waits only until at most `keep` of this wave's vector-memory operations are still in
+// flight (vmcnt retires in issue order on gfx9, loads and stores alike): the conv row loop issues
+//   LDS-DMA of row b+1 | compute row b | output stores of row b
+// and the next barrier needs the DMA, not the stores - a plain __syncthreads() waits vmcnt(0), i.e. one HBM write
+// round trip per batch row.  `keep` is wave-uniform.
+__device__ __forceinline__ void barrier_keep_vm(int keep) {
+  switch (keep) {
+    case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+  }
 }
 
 // ---------------------------------------------------------------- pixel decode
@@ -870,10 +888,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
 // refill, yet slower (276 vs 248 us: sixteen waves coupled by one barrier run their MFMA and GELU phases in step);
 // NWV = 4 (FTN_MLP_W4=1) = three 64-pixel workgroups per CU, twice the weight stream, the same time.
 // PFD = fragment reads issued PFD steps ahead of their MFMAs (FTN_MLP_PFD=2: no gain - the waves do not wait on LDS).
-template <int ACT, bool XVEC, int NS, int SKM, int SCP, int OTM, int NWV, int PFD = 1>
+template <int ACT, bool XVEC, int NS, int SKM, int SCP, int OTM, int NWV, int PFD = 1, bool SPLIT = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void k_mlp_bf_u1(MlpBfArgs a) {
   constexpr int NFR = 2 * SKM + 2 * SCP + OTM;
+  constexpr int NL1 = 2 * SKM + 2 * SCP;        // fragments of layer 1 (+ residual); the other OTM are layer 2's
   constexpr int NBUF = NWV == 16 ? 2 : 1;
+  static_assert(!SPLIT || (NBUF == 1 && PFD == 1), "SPLIT is the single-buffer, one-ahead form");
   extern __shared__ __attribute__((aligned(16))) char wlb[];
   const FtnDesc* __restrict__ d = a.desc;
   const int N = a.B * d->total_px;
@@ -890,6 +910,26 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
                                        (__attribute__((address_space(3))) void*)(dst + (size_t)piece * 1024), 16, 0, 0);
   };
+  // SPLIT: LDS = [layer-1 fragments, two buffers][layer-2 fragments, one buffer][biases].  A chunk's layer-2 fragments
+  // and the NEXT chunk's layer-1 fragments are requested at the top of the chunk and land while layer 1 runs; the
+  // barrier between the layers waits (counted vmcnt) for the former only.  Two barriers per chunk as before, but no
+  // wave ever waits for a refill it has just issued - that wait was 17 % of the launch (ablation).
+  constexpr int l1sz = NL1 * 3 * 1024, l2sz = OTM * 3 * 1024;
+  auto dma_l1 = [&](int hc, int buf) {
+    const __bf16* __restrict__ src = a.cfrag + (size_t)hc * NFR * 3 * 512;
+    char* dst = wlb + (size_t)buf * l1sz;
+    for (int piece = wv; piece < NL1 * 3; piece += NWV)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(dst + (size_t)piece * 1024), 16, 0, 0);
+  };
+  auto dma_l2 = [&](int hc) {
+    const __bf16* __restrict__ src = a.cfrag + ((size_t)hc * NFR + NL1) * 3 * 512;
+    char* dst = wlb + 2 * l1sz;
+    for (int piece = wv; piece < OTM * 3; piece += NWV)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(dst + (size_t)piece * 1024), 16, 0, 0);
+  };
+  const int n1_mine = (NL1 * 3 - wv + NWV - 1) / NWV;          // layer-1 pieces this wave requests per chunk
   const Px px = decode_px16(d, a.x, a.B, a.L, a.C, n0, j, N);
   const int CP = a.CP;
   const int kmg = a.KM >> 4;
@@ -910,9 +950,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
     xraw[s][1] = load_x4<XVEC>(px.xrow, 32 * s + 8 * qa + 4, a.C);
   }
   __builtin_amdgcn_sched_barrier(0);
-  dma_chunk(0);
+  if (SPLIT) dma_l1(0, 0);
+  else dma_chunk(0);
   const int FPc = a.n_hchunks * 32;
-  float* __restrict__ bias_l = (float*)(wlb + (size_t)NBUF * bufsz);
+  float* __restrict__ bias_l = (float*)(wlb + (SPLIT ? (size_t)(2 * l1sz + l2sz) : (size_t)NBUF * bufsz));
   for (int i = threadIdx.x; i < 2 * FPc; i += NWV * 64) {
     const int c = i < FPc ? i : i - FPc;
     bias_l[i] = c < a.FP ? (i < FPc ? a.bo[c] : a.br[c]) : 0.f;
@@ -937,6 +978,62 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
 #pragma unroll
   for (int o = 0; o < OTM; ++o) oacc[o] = *(const f4*)(a.bc + 16 * o + 4 * qa);
   __syncthreads();
+  if constexpr (SPLIT) {
+    for (int hc = 0; hc < a.n_hchunks; ++hc) {
+      const bool nxt = hc + 1 < a.n_hchunks;
+      dma_l2(hc);                                    // last read in chunk hc - 1's layer 2 (every wave is past its end barrier)
+      if (nxt) dma_l1(hc + 1, (hc + 1) & 1);         // that buffer was last read in chunk hc - 1's layer 1
+      const char* __restrict__ wl1 = wlb + (size_t)(hc & 1) * l1sz + lane * 16;
+      const char* __restrict__ wl2 = wlb + 2 * l1sz + lane * 16;
+      f4 bo_t[2], br_t[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bo_t[t] = *(const f4*)(bias_l + 16 * (hc * 2 + t) + 4 * qa);
+        br_t[t] = *(const f4*)(bias_l + FPc + 16 * (hc * 2 + t) + 4 * qa);
+      }
+      f4 h[2] = {bo_t[0], bo_t[1]};
+      bf8 hp[NS];
+      bf8 fr[2][NWP];
+      auto ldfrag = [&](int f, bf8 (&ap)[NWP]) {
+        const char* __restrict__ base = f < NL1 ? wl1 + (size_t)f * 3 * 1024 : wl2 + (size_t)(f - NL1) * 3 * 1024;
+#pragma unroll
+        for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(base + (size_t)pz * 1024);
+      };
+      auto step = [&](int f) {
+        if (f + 1 < NFR) ldfrag(f + 1, fr[(f + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf8 (&cur)[NWP] = fr[f & 1];
+        if (f < SKM) h[0] = chain_bf<NS>(cur, mp[f < SKM ? f : 0], h[0]);
+        else if (f < 2 * SKM) h[1] = chain_bf<NS>(cur, mp[f < 2 * SKM ? f - SKM : 0], h[1]);
+        else if (f < 2 * SKM + SCP) h[0] = chain_bf<NS>(cur, xp[f < 2 * SKM + SCP ? f - 2 * SKM : 0], h[0]);
+        else if (f < NL1) h[1] = chain_bf<NS>(cur, xp[f < NL1 ? f - 2 * SKM - SCP : 0], h[1]);
+        else oacc[f < NFR ? f - NL1 : 0] = chain_bf<NS>(cur, hp, oacc[f < NFR ? f - NL1 : 0]);
+        if (f == SKM - 1) h[0] = NS == 2 ? act4<ACT>(h[0] * a.inv_o) * a.sc_r + br_t[0] : act4<ACT>(h[0]) + br_t[0];
+        if (f == 2 * SKM - 1) h[1] = NS == 2 ? act4<ACT>(h[1] * a.inv_o) * a.sc_r + br_t[1] : act4<ACT>(h[1]) + br_t[1];
+        if (f == 2 * SKM + SCP - 1) h[0] = act4<ACT>(NS == 2 ? h[0] * a.inv_r : h[0]);
+        if (f == NL1 - 1) {
+          h[1] = act4<ACT>(NS == 2 ? h[1] * a.inv_r : h[1]);
+          float hv[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { hv[e] = h[0][e]; hv[4 + e] = h[1][e]; }
+          split_pieces<NS>(hv, hp);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if (active) {
+        ldfrag(0, fr[0]);
+#pragma unroll
+        for (int f = 0; f < NL1 - 1; ++f) step(f);       // these steps read layer-1 fragments only (incl. the prefetch)
+      }
+      // layer 2's fragments have landed on every wave; the next chunk's layer-1 pieces (issued behind them) stay in flight
+      barrier_keep_vm(nxt ? n1_mine : 0);
+      if (active) {
+#pragma unroll
+        for (int f = NL1 - 1; f < NFR; ++f) step(f);     // the last layer-1 step prefetches the first layer-2 fragment
+      }
+      barrier_keep_vm(0);                              // every wave is done with both buffers; the next layer-1 set has landed
+    }
+  } else
   for (int hc = 0; hc < a.n_hchunks; ++hc) {
     const char* __restrict__ wl = wlb + (size_t)(NBUF == 2 ? (hc & 1) : 0) * bufsz + lane * 16;
     // double-buffered: the other buffer was last read in chunk hc - 1, which every wave left at the barrier
@@ -1003,17 +1100,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
   }
 }
 
-template <int ACT, int NS, int SKM, int SCP, int OTM, int NWV, int PFD = 1>
+template <int ACT, int NS, int SKM, int SCP, int OTM, int NWV, int PFD = 1, bool SPLIT = false>
 static int launch_mlp_bf_u1w(MlpBfArgs ma, bool xvec, long long Nmax, hipStream_t st) {
   ma.dbg = nullptr; ma.dbg_cap = 0;
-  const size_t lds = (size_t)ma.per_chunk * 3 * 1024 * (NWV == 16 ? 2 : 1) + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
+  const size_t lds = (SPLIT ? (size_t)(2 * (2 * SKM + 2 * SCP) + OTM) * 3 * 1024
+                            : (size_t)ma.per_chunk * 3 * 1024 * (NWV == 16 ? 2 : 1)) + (size_t)ma.n_hchunks * 32 * 2 * sizeof(float);
   if (lds > 160 * 1024) { ftn_set_error("stage C needs %zu B of LDS", lds); return -1; }
   const int nblk = (int)((Nmax + NWV * 16 - 1) / (NWV * 16));
-  hipError_t e = xvec ? hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV, PFD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                      : hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV, PFD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = xvec ? hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV, PFD, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                      : hipFuncSetAttribute((const void*)k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV, PFD, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_bf_u1): %s", hipGetErrorString(e)); return (int)e; }
-  if (xvec) hipLaunchKernelGGL((k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV, PFD>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
-  else hipLaunchKernelGGL((k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV, PFD>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
+  if (xvec) hipLaunchKernelGGL((k_mlp_bf_u1<ACT, true, NS, SKM, SCP, OTM, NWV, PFD, SPLIT>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
+  else hipLaunchKernelGGL((k_mlp_bf_u1<ACT, false, NS, SKM, SCP, OTM, NWV, PFD, SPLIT>), dim3(nblk), dim3(NWV * 64), lds, st, ma);
   FTN_CHECK_LAUNCH();
   return 0;
 }
@@ -1028,6 +1126,10 @@ static int launch_mlp_bf_u1(const MlpBfArgs& ma, bool xvec, long long Nmax, hipS
   if constexpr (NS == 2 && OTM <= 7) {
     if (g_mlp_pfd2) return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 8, 2>(ma, xvec, Nmax, st);
   }
+  // default: split refill where two workgroups' LDS still fit a CU (or, for the d_model-128 shape, one does)
+  if (g_mlp_split && ma.per_chunk == 2 * SKM + 2 * SCP + OTM &&
+      (size_t)(2 * (2 * SKM + 2 * SCP) + OTM) * 3 * 1024 + (size_t)ma.n_hchunks * 256 <= (OTM <= 7 ? 80 : 160) * 1024)
+    return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 8, 1, true>(ma, xvec, Nmax, st);
   return launch_mlp_bf_u1w<ACT, NS, SKM, SCP, OTM, 8>(ma, xvec, Nmax, st);
 }
 
@@ -1542,23 +1644,6 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
 //     once per tile: bit s of vmask[u] = tap 2s + (lane half) is inside the grid for this lane's pixel;
 //   * the region planes sit CBF_FAST_PLANE bytes apart (a constant), so the second piece is a ds_read offset.
 // That leaves ~10 VALU per slab: v_bfe, v_add, v_mad per pixel unit and one select for the tap offset.
-// Workgroup barrier that waits only until at most `keep` of this wave's vector-memory operations are still in
-// flight (vmcnt retires in issue order on gfx9, loads and stores alike): the conv row loop issues
-//   LDS-DMA of row b+1 | compute row b | output stores of row b
-// and the next barrier needs the DMA, not the stores - a plain __syncthreads() waits vmcnt(0), i.e. one HBM write
-// round trip per batch row.  `keep` is wave-uniform.
-__device__ __forceinline__ void barrier_keep_vm(int keep) {
-  switch (keep) {
-    case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-  }
-}
-
 // A plane = the region's pixels + a 256-byte block of zeros (one 16-byte slot per LDS bank quad) that taps outside
 // the grid are redirected to.  A redirected lane reads the slot of ITS OWN would-be address ((addr & 0xF0) in the
 // block), so it keeps the bank quad it would have used and a ds_read_b128 lane group stays conflict-free; with one
