@@ -1761,7 +1761,7 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   if (row_lo >= row_hi) return;
   const int kh = a.kh[br], kw = a.kw[br], hy = kh >> 1, hx = kw >> 1, ntaps = kh * kw;
   const int S = (ntaps + 1) >> 1;
-  if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) { a.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime(); a.dbg[wgid * 8 + 4] = (unsigned long long)ntaps; a.dbg[wgid * 8 + 5] = 0; }
+  if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) { a.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime(); a.dbg[wgid * 8 + 4] = (unsigned long long)ntaps; a.dbg[wgid * 8 + 5] = ((unsigned long long)row_lo << 32) | (unsigned)row_hi; }
   char* __restrict__ wl = ldsb;
   char* __restrict__ rbuf0 = ldsb + (size_t)S * 3 * 1024;      // behind THIS branch's weight fragments
   static_assert(CBF_FAST_ZBASE % 256 == 0, "the zero block must start on a 256-byte boundary");
@@ -2547,7 +2547,7 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
   ca.region_bytes = gm.region_bytes;
   ca.wbytes = gm.wbytes;
   ca.sgroup = gm.sgroup;
-  ca.dbg = (g_stamp_which & 1) ? g_stamp_buf : nullptr; ca.dbg_cap = g_stamp_cap;
+  ca.dbg = ((g_stamp_which & 1) && (!(g_stamp_which & 4) || ca.bt_L > 0)) ? g_stamp_buf : nullptr; ca.dbg_cap = g_stamp_cap;   // which & 4: stage B only
   // batch rows per (persistent) workgroup: as many as still leave ~2 workgroups per CU in the launch - each
   // staging of a tile's weights and pixel bookkeeping is shared by the rows (8 rows: -3 % against 4 at B = 256)
   ca.bpw = 1;

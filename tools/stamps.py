@@ -30,7 +30,7 @@ with torch.inference_mode():
     torch.cuda.synchronize()
     nwg = 2_000_000
     buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
-    lib.ftn_debug_stamps(buf.data_ptr(), buf.numel(), 1 if which == 'conv' else 2)
+    lib.ftn_debug_stamps(buf.data_ptr(), buf.numel(), (5 if len(sys.argv) > 2 and sys.argv[2] == 'B' else 1) if which == 'conv' else 2)
     blk(x)
     torch.cuda.synchronize()
     lib.ftn_debug_stamps(None, 0, 0)
@@ -43,7 +43,7 @@ s = s[live].astype(np.float64)
 t0 = s[:, 0].min()
 print("live workgroups", len(s))
 if which == "conv":
-    xcc = s[:, 5].astype(int) & 15
+    xcc = np.zeros(len(s), dtype=int)
     for xid in sorted(set(xcc)):
         m = xcc == xid
         print(f"  xcc {xid}: n={m.sum():4d} start {(s[m,6].min()-s[:,6].min())/100:7.1f} us  end {(s[m,7].max()-s[:,6].min())/100:7.1f} us")
@@ -63,3 +63,28 @@ if which == "conv":
         m = s[:, 4] == taps
         print(f"taps {taps:3d}: n={m.sum():5d} stage {np.mean(s[m,1]-s[m,0]):8.0f} compute {np.mean(s[m,2]-s[m,1]):8.0f} "
               f"total {np.mean(s[m,3]-s[m,0]):8.0f}  start-span {s[m,0].min()-t0:9.0f}..{s[m,0].max()-t0:9.0f}")
+if which == "conv":
+    tot = s[:, 3] - s[:, 0]
+    order = np.argsort(-tot)[:12]
+    print("slowest workgroups: (index in live list, taps, start offset us, total cycles, first-row stage cycles)")
+    for i in order:
+        print(f"  {i:4d} taps {int(s[i,4]):3d} start {(s[i,6]-s[:,6].min())/100:6.1f} us  end {(s[i,7]-s[:,6].min())/100:6.1f} us  total {tot[i]:9.0f}  stage {s[i,1]-s[i,0]:9.0f}")
+    for taps in sorted(set(s[:, 4].astype(int))):
+        m = s[:, 4] == taps
+        e = (s[m, 7] - s[:, 6].min()) / 100
+        print(f"taps {taps:3d}: end time us p10 {np.percentile(e,10):6.1f} p50 {np.median(e):6.1f} p90 {np.percentile(e,90):6.1f} max {e.max():6.1f}; start max {((s[m,6]-s[:,6].min())/100).max():5.1f}")
+
+if which == "conv":
+    raw = buf.cpu().numpy().reshape(-1, 8)[(buf.cpu().numpy().reshape(-1, 8)[:, 6] > 0)]
+    raw = raw[raw[:, 3] > 0]
+    lo = (raw[:, 5] >> 32).astype(np.int64); hi = (raw[:, 5] & 0xffffffff).astype(np.int64)
+    nrows = hi - lo
+    tile0 = lo // B; tile1 = (hi - 1) // B
+    tot = (raw[:, 3] - raw[:, 0]).astype(np.float64)
+    for taps in sorted(set(raw[:, 4].astype(int))):
+        m = raw[:, 4] == taps
+        print(f"taps {taps}: rows/wg {nrows[m].min()}..{nrows[m].max()}")
+        for t in sorted(set(tile0[m])):
+            mm = m & (tile0 == t) & (tile1 == t)
+            if mm.sum():
+                print(f"    tile {t}: n={mm.sum():3d} cycles/row {np.mean(tot[mm]/nrows[mm]):8.0f}  total p50 {np.median(tot[mm]):9.0f}")
