@@ -38,6 +38,7 @@ static size_t g_stamp_cap = 0;
 static int g_stamp_which = 0;  // 1: k_conv, 2: k_mlp
 static const bool g_conv_generic = [] { const char* e = getenv("FTN_CONV_GENERIC"); return e != nullptr && e[0] == '1'; }();  // experiment switch
 static const bool g_mlp_split = [] { const char* e = getenv("FTN_MLP_SPLIT"); return e == nullptr || e[0] != '0'; }();   // split refill (default on)
+static const bool g_r_keeps_x = [] { const char* e = getenv("FTN_R_KEEPS_X"); return e == nullptr || e[0] != '0'; }();   // stage C leaves x inside R (default on)
 static const bool g_mlp_pfd2 = [] { const char* e = getenv("FTN_MLP_PFD"); return e != nullptr && e[0] == '2'; }();   // experiment: fragment reads two steps ahead
 static const bool g_mlp_w16 = [] { const char* e = getenv("FTN_MLP_W16"); return e != nullptr && e[0] == '1'; }();   // experiment: 16-wave double-buffered k_mlp_bf_u1
 static const bool g_mlp_w4 = [] { const char* e = getenv("FTN_MLP_W4"); return e != nullptr && e[0] == '1'; }();     // experiment: 4-wave workgroups, three per CU
@@ -596,6 +597,7 @@ struct MlpBfArgs {
   // bc then point at biases prescaled the same way): z = acc_o * inv_o;  acc_r starts as act(z) * sc_r + br~
   // and g = act(acc_r * inv_r);  a' = acc * inv_a (tiles < n_oa),  r = acc * inv_r2 - x.  All 1 otherwise.
   float inv_o, sc_r, inv_r, inv_a, inv_r2;
+  int r_keeps_x;         // 1: outR = res2(g) + b (x NOT subtracted: k_out takes it out once, OutArgs.r_keeps_x)
   unsigned long long* dbg; size_t dbg_cap;
 };
 
@@ -1095,7 +1097,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
     } else {
       const int ch = 16 * (o - a.n_oa) + 4 * qa;
       const f4 rv = NS == 2 ? oacc[o] * a.inv_r2 : oacc[o];
-      *(f4*)(a.outR + (size_t)px.n * CP + ch) = rv - load_x4<XVEC>(px.xrow, ch, a.C);
+      *(f4*)(a.outR + (size_t)px.n * CP + ch) = a.r_keeps_x ? rv : rv - load_x4<XVEC>(px.xrow, ch, a.C);
     }
   }
 }
@@ -1964,6 +1966,9 @@ struct OutArgs {
   const float* ln_g;     // optional fused epilogue (FAST path): y = LayerNorm_C(x + ((x + comb) - x)), the
   const float* ln_b;     // per-block residual + shared LayerNorm of TimesNet.forward (reference :2050-2058)
   float ln_eps;
+  int r_keeps_x;         // R holds res2(g) + b, not res2(g) + b - x: y = x + (sum_g w_g (e_g + R_g) - (sum_g w_g) x).  Stage C then
+                         // never re-reads x (93 MB of its 286 MB of fetches at the bench shape); fp32 activations only -
+                         // for half inputs every per-group delta is rounded, so x must come off before the weighting
   int act_dtype;         // 1 bf16 / 2 fp16 input: the reference rounds every per-group delta, each weighted
                          // term, their sum and x + sum to the input dtype (:1068-1069, :1092, :818); 0 = fp32
 };
@@ -2106,6 +2111,9 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
       }
     };
     if (G > 0) load_m(0, mc);
+    float wsum[NPX];
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) wsum[u] = 0.f;
     for (int g = 0; g < G; ++g) {
       f4 rr[4][NPX], mn[3][NPX];
       float w[NPX];
@@ -2115,6 +2123,7 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
 #pragma unroll
         for (int o = 0; o < 4; ++o) rr[o][u] = o < n_ot ? *(const f4*)(row + 16 * o) : f4{0.f, 0.f, 0.f, 0.f};
         w[u] = a.wts[(size_t)bb[u] * FTN_KMAX + g];
+        wsum[u] += w[u];
       }
       load_m(g + 1 < G ? g + 1 : g, mn);
       f4 z[4][NPX];
@@ -2158,6 +2167,7 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
             for (int r = 0; r < 4; ++r)
               if (ch + r < a.C) xv[r] = a.x[e0 + r];
           }
+          if (a.r_keeps_x) yacc[o][u] = yacc[o][u] - xv * wsum[u];      // the x that stage C left inside every R_g
           const f4 nv = a.act_dtype == 0 ? xv + yacc[o][u] : rnd_act4(xv + rnd_act4(yacc[o][u], a.act_dtype), a.act_dtype);
           yacc[o][u] = ln ? xv + (nv - xv) : nv;
         }
@@ -2716,6 +2726,10 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     const bool mlp_bf128 = use_bf && !mlp_bf && pl->res1 && pl->res2 && CA == 96 && CP == 128 && n_ot_c == 14 &&
                            pl->cfragbf_per_chunk == 28 &&
                            (size_t)28 * 3 * 1024 + (size_t)pl->n_hchunks * 32 * 2 * sizeof(float) <= 160 * 1024;
+    // the u1 stage C of the d_model-64 shape with the FAST k_out behind it and fp32 activations: R keeps its x
+    // (OutArgs.r_keeps_x); every other combination subtracts x in stage C as the reference's delta does
+    const bool r_keeps_x = mlp_bf && g_mlp_u1 && g_r_keeps_x && act_dtype == 0 && (CA + 31) / 32 == 2 && (CP + 31) / 32 == 2 &&
+                           n_ot_c == 7 && CA <= 48 && CP <= 64;
     if (use_bf) {
       cb.in = (const __bf16*)bufA; cb.bt_L = L; cb.out = buf1; cb.out_p3 = (mlp_bf || mlp_bf128) ? 1 : 0; cb.bias = wb + (h2 ? pl->b_conv1s : pl->b_conv1); cb.desc = desc;
       cb.B = B; cb.INC = CA; cb.OUTC = CA; cb.nbr = pl->nbr; cb.cin = pl->MP; cb.cout = pl->MP;
@@ -2781,6 +2795,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
       mb.bc = wb + (h2 ? pl->b_c2s : pl->b_c2);
       mb.inv_o = h2 ? 1.0f / pl->sc_out1 : 1.0f; mb.sc_r = h2 ? pl->sc_res1 : 1.0f; mb.inv_r = h2 ? 1.0f / pl->sc_res1 : 1.0f;
       mb.inv_a = h2 ? 1.0f / pl->sc_a2 : 1.0f; mb.inv_r2 = h2 ? 1.0f / pl->sc_r2 : 1.0f;
+      mb.r_keeps_x = r_keeps_x ? 1 : 0;
       mb.outA = (__bf16*)buf0; mb.outR = bufR; mb.desc = desc;
       mb.B = B; mb.L = L; mb.C = C; mb.CP = CP; mb.FP = FP; mb.KM = CA; mb.AC = CA;
       mb.nsKM = (CA + 31) / 32; mb.nsCP = (CP + 31) / 32;
@@ -2813,6 +2828,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     OutArgs oa = {};
     oa.x = x; oa.y = y; oa.m = buf1; oa.R = bufR; oa.W = wb + pl->w_out2; oa.bias = wb + pl->b_out2; oa.wts = wts;
     oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CA; oa.act_dtype = act_dtype;
+    oa.r_keeps_x = r_keeps_x ? 1 : 0;
     const bool fast = CA <= 48 && CP <= 64;
     if (fast) { oa.ln_g = ln_g; oa.ln_b = ln_b; oa.ln_eps = ln_eps; ln_g = nullptr; }   // fused epilogue
     // FAST path: 16 pixels per wave (3 waves/SIMD; with 32 the kernel needs > 256 registers -> 1 wave/SIMD)
