@@ -196,6 +196,45 @@ def test_error_conventions(ftn):
         T.LowRankTemporalContext(3)(torch.zeros(1, 2, 4), 8)
 
 
+def test_c_abi_rejects_bad_arguments_before_any_launch(ftn):
+    """Argument checks of the C ABI run on the host before anything is enqueued, so they can be exercised without a
+    GPU: error code < 0 and a message in ftn_last_error()."""
+    import ctypes as C
+
+    lib = ftn.lib.load()
+    sd = ftn.synth.make_inception_params(16, 32, [(3, 3)], 2.0, 0)
+    blob, plan = ftn.pack.pack_inception(sd, 16, 32, [(3, 3)], 2.0, "gelu", "f16x2")
+    B, L = 2, 48
+    mg = C.c_int(0)
+    pxb = lib.ftn_selector_px_bound(L, 2, L, 1, C.byref(mg))
+    assert pxb > 0 and mg.value >= 1
+    need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, mg.value, pxb)
+    assert need > 0
+    fake = 1 << 20                                        # a non-null, 256-aligned "device pointer": never dereferenced
+    # fused finalize + stage A: nothing to do (psum and x both NULL)
+    rc = lib.ftn_period_finalize_stage_a(None, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake, fake, None,
+                                         C.byref(plan), fake, mg.value, pxb, fake, need, None)
+    assert rc < 0 and b"nothing to do" in lib.ftn_last_error()
+    # workspace too small
+    rc = lib.ftn_period_finalize_stage_a(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake, fake, fake,
+                                         C.byref(plan), fake, mg.value, pxb, fake, need - 1, None)
+    assert rc < 0 and b"workspace" in lib.ftn_last_error()
+    # misaligned amps / weights
+    rc = lib.ftn_period_finalize(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake + 4, fake, None)
+    assert rc < 0 and b"aligned" in lib.ftn_last_error()
+    # unknown flag bit / stage-A flag on a plan that is not a bottleneck block
+    rc = lib.ftn_timesblock_forward(fake, fake, B, L, C.byref(plan), fake, fake, fake, mg.value, pxb, 0, 2, fake, need, None)
+    assert rc < 0 and b"flags" in lib.ftn_last_error()
+    sd1 = ftn.synth.make_inception_params(16, 16, [(3, 3)], 1.0, 0)
+    _, plan1 = ftn.pack.pack_inception(sd1, 16, 16, [(3, 3)], 1.0, "gelu", "f32")
+    need1 = lib.ftn_timesblock_workspace_bytes(C.byref(plan1), B, L, mg.value, pxb)
+    rc = lib.ftn_timesblock_forward(fake, fake, B, L, C.byref(plan1), fake, fake, fake, mg.value, pxb, 0, 1, fake, need1, None)
+    assert rc < 0 and b"flags" in lib.ftn_last_error()
+    rc = lib.ftn_period_finalize_stage_a(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake, fake, fake,
+                                         C.byref(plan1), fake, mg.value, pxb, fake, max(need, need1), None)
+    assert rc < 0 and b"bottleneck" in lib.ftn_last_error()
+
+
 # ---- torch backend of the mirrors vs golden ----------------------------------
 def _block(ftn, case):
     T = ftn.models.timesnet
