@@ -2550,7 +2550,8 @@ static int launch_conv_bf_fast(const ConvBfArgs& ca, const ConvBfGeom& gm, dim3 
   return 0;
 }
 
-static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_x, int nsplit, hipStream_t st) {
+static const bool g_conv_quant = [] { const char* e = getenv("FTN_CONV_QUANT"); return e == nullptr || e[0] != '0'; }();
+static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_x, int nsplit, hipStream_t st, int rows_est = 0) {
   const int nco_tot = ca.cout / 16;
   ca.nchunk = ftn_cdiv(nco_tot, gm.NCO);
   ca.plane_bytes = gm.plane_bytes;
@@ -2591,6 +2592,44 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
     for (int k = 0; k < ca.nbr; ++k) { nwg[k] = (int)(ncu * cost[k] / tot); if (nwg[k] < 1) nwg[k] = 1; used += nwg[k]; }
     for (int k = 0; used < ncu; k = (k + 1) % ca.nbr) { ++nwg[k]; ++used; }     // leftovers round-robin from the first branch
     for (int k = 0; used > ncu && k < ca.nbr; ++k) while (nwg[k] > 1 && used > ncu) { --nwg[k]; --used; }
+    // Rows are whole units: a 7x7 workgroup with 11 rows ends 9 % after one with 10 (tools/stamps.py: the launch
+    // ended at 79 us with the median workgroup done at 66).  With an estimate of the row count (the descriptor is on
+    // the device: groups bound x tiles of a typical grid x batch rows) pick the split that minimises
+    // max_k ceil(rows / nwg_k) * cost_k; a wrong estimate only costs balance, the kernel derives the ranges itself.
+    if (rows_est > 0 && g_conv_quant) {
+      double bestT = 1e300;
+      int best[FTN_MAXBR];
+      bool found = false;
+      for (int kk = 0; kk < ca.nbr; ++kk) {
+        for (int r = 1; r <= rows_est; ++r) {
+          const double T = r * cost[kk];
+          if (T >= bestT) break;
+          int need[FTN_MAXBR], sum = 0;
+          bool ok = true;
+          for (int k = 0; k < ca.nbr && ok; ++k) {
+            const int per = (int)(T / cost[k] + 1e-9);
+            if (per < 1) { ok = false; break; }
+            need[k] = (rows_est + per - 1) / per;
+            sum += need[k];
+          }
+          if (ok && sum <= ncu) { bestT = T; for (int k = 0; k < ca.nbr; ++k) best[k] = need[k]; found = true; break; }
+        }
+      }
+      if (found) {
+        int sum = 0;
+        for (int k = 0; k < ca.nbr; ++k) sum += best[k];
+        // spare workgroups go where they shorten the longest branch next
+        while (sum < ncu) {
+          int arg = 0; double worst = -1.0;
+          for (int k = 0; k < ca.nbr; ++k) {
+            const double t = (double)((rows_est + best[k] - 1) / best[k]) * cost[k];
+            if (t > worst) { worst = t; arg = k; }
+          }
+          ++best[arg]; ++sum;
+        }
+        for (int k = 0; k < ca.nbr; ++k) nwg[k] = best[k];
+      }
+    }
     ca.wg_off[0] = 0;
     for (int k = 0; k < ca.nbr; ++k) ca.wg_off[k + 1] = ca.wg_off[k] + nwg[k];
     const ConvBfGeom gmf = {gm.NCO, lds_fast, gm.plane_bytes, gm.region_bytes, gm.wbytes, gm.sgroup, true};
@@ -2691,6 +2730,8 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
   const long long Nmax = (long long)B * px_row;
   int tiles_row;
   worst_tiles(L, max_groups, &tiles_row);
+  // (tile, batch row) work items of a conv launch, estimated: every group present, a grid of ~L pixels each
+  const int rows_est = (int)((long long)B * max_groups * ((L + FTN_TILE_PX - 1) / FTN_TILE_PX) < (1 << 20) ? B * max_groups * ((L + FTN_TILE_PX - 1) / FTN_TILE_PX) : 0);
   const int nblk_pw = (int)(((long long)B * L + 1 + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));   // stage A: window rows + pad row
   const int nblk_ew = 2048;
   const bool yvec = ((uintptr_t)y & 15) == 0;
@@ -2744,7 +2785,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ca.in = bufA; ca.bt_L = L; ca.out = buf1; ca.bias = wb + pl->b_conv1; ca.desc = desc; ca.B = B; ca.INC = CA; ca.OUTC = CA;
     ca.nbr = pl->nbr; ca.cin = pl->MP; ca.cout = pl->MP; ca.in_stride_br = pl->MP; ca.out_stride_br = pl->MP;
     for (int k = 0; k < pl->nbr; ++k) { ca.W[k] = wb + pl->w_conv1[k]; ca.kh[k] = pl->kh[k]; ca.kw[k] = pl->kw[k]; }
-    if (use_bf) { if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st))) return rc; }
+    if (use_bf) { if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st, rows_est))) return rc; }
     else if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(2, st);
     // C: fused pointwise chain
@@ -2821,7 +2862,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     if (use_bf) {
       cb.in = (const __bf16*)buf0; cb.bt_L = 0; cb.bias = wb + (h2 ? pl->b_conv2s : pl->b_conv2); cb.out_p3 = 0;
       for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf2[k]); cb.inv[k] = h2 ? 1.0f / pl->sc_conv2[k] : 1.0f; }
-      if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st))) return rc;
+      if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st, rows_est))) return rc;
     } else if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
     prof_mark(4, st);
     // E+F: y = x + sum_g w (act(W_out2 m' + b) + r)
