@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-workgroup phase timeline of k_conv / k_mlp from s_memtime stamps
 (ftn_debug_stamps).  Usage on the GPU box: python tools/stamps.py [conv|mlp]"""
+import os
 import sys
 from pathlib import Path
 
@@ -16,7 +17,7 @@ pkg = ge.load_package()
 lib = pkg.lib.load()
 T = pkg.models.timesnet
 dev = torch.device("cuda:0")
-B, L, C, K = 256, 336, 64, 5
+B, L, C, K = int(os.environ.get('STAMP_B', '256')), 336, 64, 5
 ks = [(3, 3), (5, 5), (7, 7)]
 params = pkg.synth.make_inception_params(C, 4 * C, ks, 4.0, seed=0)
 blk = T.TimesBlock(C, ks, 0.0, "gelu", d_ff=4 * C, bottleneck_ratio=4.0)
