@@ -27,6 +27,7 @@
 // merged conv with proj folded in, and E by an elementwise epilogue.
 #include <stdlib.h>
 #include "ftn_common.h"
+#include "ftn_mlp.h"
 
 #define NPXU 4  // 16-pixel units per wave in the pointwise / conv kernels
 
@@ -154,21 +155,6 @@ __device__ __forceinline__ Px decode_px16(const FtnDesc* __restrict__ d, const f
     return p;
   }
   return decode_px(d, x, B, L, C, n0 + j, N);
-}
-
-template <bool XVEC>
-__device__ __forceinline__ f4 load_x4(const float* __restrict__ xrow, int c, int C) {
-  f4 v = {0.f, 0.f, 0.f, 0.f};
-  if (xrow == nullptr) return v;
-  if (XVEC) {
-    if (c < C) v = *(const f4*)(xrow + c);
-  } else {
-    if (c + 0 < C) v.x = xrow[c + 0];
-    if (c + 1 < C) v.y = xrow[c + 1];
-    if (c + 2 < C) v.z = xrow[c + 2];
-    if (c + 3 < C) v.w = xrow[c + 3];
-  }
-  return v;
 }
 
 // ---------------------------------------------------------------- stage A and the generic pointwise layers
@@ -580,68 +566,6 @@ __global__ __launch_bounds__(256, (NPX >= 3 ? 2 : 1)) void k_mlp(MlpArgs a) {
 // pieces in registers and become the B operand of the output projection (the host packs
 // the projection's K order to match the accumulator lane map).  512-thread workgroups
 // (256 pixels) share each chunk's weight fragments, DMA-staged and double-buffered.
-struct MlpBfArgs {
-  const float* x;
-  const __bf16* m;       // P3 [N][KM/16][3][16]
-  const __bf16* cfrag;   // [n_hchunks][per_chunk][3][512]
-  const float* bo;
-  const float* br;
-  const float* bc;
-  __bf16* outA;          // P3 [N][AC/16][3][16]
-  float* outR;           // [N][CP]
-  const FtnDesc* desc;
-  int B, L, C, CP, FP, KM, AC;
-  int nsKM, nsCP;        // K=32 slabs of layer 1 / of the residual (each <= 2)
-  int n_oa, n_ot, n_hchunks, per_chunk;
-  // f16x2 engine (NS == 2): the accumulators carry the power-of-two prescale of their weight matrix (bo / br /
-  // bc then point at biases prescaled the same way): z = acc_o * inv_o;  acc_r starts as act(z) * sc_r + br~
-  // and g = act(acc_r * inv_r);  a' = acc * inv_a (tiles < n_oa),  r = acc * inv_r2 - x.  All 1 otherwise.
-  float inv_o, sc_r, inv_r, inv_a, inv_r2;
-  int r_keeps_x;         // 1: outR = res2(g) + b (x NOT subtracted: k_out takes it out once, OutArgs.r_keeps_x)
-  unsigned long long* dbg; size_t dbg_cap;
-};
-
-template <int NS>
-__device__ __forceinline__ f4 chain_bf(const bf8 (&ap)[PxFmt<NS>::NW], const bf8 (&bp)[NS], f4 c) {
-  if constexpr (NS == 3) {
-    c = mfma_bf(ap[0], bp[2], c);
-    c = mfma_bf(ap[2], bp[0], c);
-    c = mfma_bf(ap[1], bp[1], c);
-    c = mfma_bf(ap[0], bp[1], c);
-    c = mfma_bf(ap[1], bp[0], c);
-    return mfma_bf(ap[0], bp[0], c);
-  } else if constexpr (NS == 2) {      // f16x2: A2 lo' + A3 hi + A1 hi (ftn_common.h), small terms first
-    c = mfma_h(ap[1], bp[1], c);
-    c = mfma_h(ap[2], bp[0], c);
-    return mfma_h(ap[0], bp[0], c);
-  } else {
-    return mfma_bf(ap[0], bp[0], c);
-  }
-}
-
-// eight fp32 values -> NS pieces of 8 (bf16: exact truncation split; fp16: hi + scaled remainder, ftn_common.h)
-template <int NS>
-__device__ __forceinline__ void split_pieces(const float (&v)[8], bf8 (&out)[NS]) {
-  typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  if constexpr (NS == 2) {
-    unsigned pc[2][4];
-    split_h2<8>(v, pc);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const u4 w = {pc[p][0], pc[p][1], pc[p][2], pc[p][3]};
-      out[p] = __builtin_bit_cast(bf8, w);
-    }
-  } else {
-    unsigned pc[NS][4];
-    split_trunc<NS, 8>(v, pc);
-#pragma unroll
-    for (int p = 0; p < NS; ++p) {
-      const u4 w = {pc[p][0], pc[p][1], pc[p][2], pc[p][3]};
-      out[p] = __builtin_bit_cast(bf8, w);
-    }
-  }
-}
-
 // NW = waves per workgroup.  NW = 8: one 256-pixel workgroup per CU, chunk weights double-buffered.
 // NW = 4: 128-pixel workgroups with a single weight buffer (2 x 66 KB would not fit twice), two per CU:
 // VALU and MFMA work of a SIMD serialise on gfx950 (tools/ubench/mfma_valu.hip), so what a second
@@ -1138,301 +1062,6 @@ static int launch_mlp_bf_u1(const MlpBfArgs& ma, bool xvec, long long Nmax, hipS
 template <int ACT, int NS>
 static int launch_mlp_bf_c128(const MlpBfArgs& ma, bool xvec, long long Nmax, hipStream_t st) {
   return launch_mlp_bf_u1<ACT, NS, 3, 4, 14>(ma, xvec, Nmax, st);
-}
-
-// ---------------------------------------------------------------- stage C, position-major (split engines, fp32 activations)
-// For t < L grid pixel t of EVERY period group is window position (b, t), and two of stage C's four
-// matrix products do not depend on the group at all:
-//   res1(x) = W_res1 x + b           depends on (b, t) only                                   (:645-647)
-//   sum_g w[b,g] res2(g_g) = W_res2 (sum_g w[b,g] g_g) + b sum_g w[b,g]      by linearity     (:1075-1092 over :651-654)
-// So a wave owns 16 window positions and walks the period groups INSIDE the hidden-chunk loop: per 32-channel chunk
-// res1 once, then per group  h = W_out1 m_g + b;  g_g = act(act(h) + res1);  a'_g += W_in2 g_g;  s += w_g g_g,  and
-// W_res2 s once.  155 648 instead of 286 720 multiply-adds per window position at the bench shape (five groups), one
-// weight refill / barrier pair per chunk for five groups' worth of work, x read once, and the per-pixel residual
-// tensor R_g (written here, re-read by k_out: ~220 MB per step) shrinks to one [B*L][CP] tensor that already holds
-// the weighted group sum.  Groups are processed GB at a time (registers: 28 per group at d_model 64); more than GB
-// groups run as several batches that recompute res1 and add into the same R accumulators.
-// The tail pixels t >= L of a grid (live zero inputs that feed the second conv's halo, never the output) have no
-// window position: the blocks past n_main walk them as one-group units with x = 0 and no R.
-struct MlpPosArgs {
-  MlpBfArgs c;
-  const float* wts;      // [B][FTN_KMAX] softmax group weights w[b,g] (finalize kernel)
-  float* outRs;          // [B*L][CP]: sum_g w[b,g] (res2(g_g) + b_res2)   (x NOT subtracted: OutArgs.r_summed)
-  int n_main, n_tail;    // blocks [0, n_main) own window positions, [n_main, n_main + n_tail) the tail pixels
-};
-
-template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF>
-__global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
-  const MlpBfArgs& a = pa.c;
-  constexpr int NL1 = 2 * SKM + 2 * SCP, NFR = NL1 + NOA + NOR;
-  constexpr int NWP = PxFmt<NS>::NW, PXE = PxFmt<NS>::ELEMS;
-  constexpr int bufsz = NFR * 3 * 1024;
-  extern __shared__ __attribute__((aligned(16))) char wlb[];
-  const FtnDesc* __restrict__ d = a.desc;
-  const int G = d->n_groups, B = a.B, L = a.L;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const bool tail_blk = (int)blockIdx.x >= pa.n_main;
-  const int UPR = (L + 15) >> 4;
-  int TU = 0;                                                   // tail units per batch row
-  if (tail_blk)
-    for (int g = 0; g < G; ++g) TU += (d->g_pad[g] + 15) >> 4;
-  const int n_tail_units = B * TU;
-  const int tv0 = ((int)blockIdx.x - pa.n_main) * NWV, tvstep = pa.n_tail * NWV;
-  const int iters = tail_blk ? (tv0 < n_tail_units ? (n_tail_units - tv0 + tvstep - 1) / tvstep : 0) : (G + GB - 1) / GB;
-  if (tail_blk && iters == 0) return;
-
-  // ---- this wave's window positions (main blocks)
-  const int u = __builtin_amdgcn_readfirstlane((int)blockIdx.x * NWV + wave);
-  const bool active_m = !tail_blk && u < B * UPR;
-  const int uc = active_m ? u : 0;
-  const int bm = uc / UPR, t0m = (uc - bm * UPR) * 16;
-  const bool ok_m = active_m && t0m + j < L;
-  const int tcm = t0m + j < L ? t0m + j : L - 1;
-
-  auto dma_chunk = [&](int hc, int buf) {
-    const __bf16* __restrict__ src = a.cfrag + (size_t)hc * NFR * 3 * 512;
-    char* dst = wlb + (size_t)buf * bufsz;
-    for (int piece = wv; piece < NFR * 3; piece += NWV)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)piece * 512 + lane * 8),
-                                       (__attribute__((address_space(3))) void*)(dst + (size_t)piece * 1024), 16, 0, 0);
-  };
-  const int FPc = a.n_hchunks * 32;
-  float* __restrict__ bias_l = (float*)(wlb + (size_t)NBUF * bufsz);
-  for (int i = threadIdx.x; i < 2 * FPc; i += NWV * 64) {
-    const int c = i < FPc ? i : i - FPc;
-    bias_l[i] = c < a.FP ? (i < FPc ? a.bo[c] : a.br[c]) : 0.f;
-  }
-  const int kmg = a.KM >> 4;
-
-  // ---- x pieces (main blocks; the tail pixels are live zeros): split once, parked in this wave's own LDS slab
-  // (lane-linear, read back once per hidden chunk - 16 registers that the group loop needs more) ; R accumulators
-  char* __restrict__ xl = wlb + (size_t)NBUF * bufsz + (size_t)2 * FPc * sizeof(float) + (size_t)wave * (SCP * NS * 1024) + lane * 16;
-  {
-    const float* __restrict__ xrow = active_m ? a.x + ((size_t)bm * L + tcm) * a.C : nullptr;
-#pragma unroll
-    for (int s = 0; s < SCP; ++s) {
-      const f4 x0 = load_x4<XVEC>(xrow, 32 * s + 8 * qa, a.C), x1 = load_x4<XVEC>(xrow, 32 * s + 8 * qa + 4, a.C);
-      const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      bf8 xp[NS];
-      split_pieces<NS>(xv, xp);
-#pragma unroll
-      for (int pz = 0; pz < NS; ++pz) *(bf8*)(xl + (size_t)(s * NS + pz) * 1024) = xp[pz];
-    }
-  }
-  float wsum = 0.f;
-  if (active_m)
-    for (int g = 0; g < G; ++g) wsum += pa.wts[(size_t)bm * FTN_KMAX + g];
-  f4 racc[NOR];
-#pragma unroll
-  for (int o = 0; o < NOR; ++o) racc[o] = *(const f4*)(a.bc + 16 * (NOA + o) + 4 * qa) * wsum;
-
-  for (int it = 0; it < iters; ++it) {
-    // ---- the groups of this pass: flat pixel index n = base[i] + tc (base wave-uniform)
-    int gcnt, tc;
-    bool ok;
-    int base[GB];
-    float wg[GB];
-    if (!tail_blk) {
-      const int g_lo = it * GB;
-      gcnt = G - g_lo < GB ? G - g_lo : GB;
-      if (!active_m) gcnt = 0;
-      tc = tcm; ok = ok_m;
-#pragma unroll
-      for (int i = 0; i < GB; ++i) {
-        const int g = g_lo + i < G ? g_lo + i : G - 1;
-        const int off = d->g_px_off[g], P = d->g_px_off[g + 1] - off;
-        base[i] = B * off + bm * P;
-        wg[i] = i < gcnt ? pa.wts[(size_t)bm * FTN_KMAX + g] : 0.f;
-      }
-    } else {
-      const int v = __builtin_amdgcn_readfirstlane(tv0 + it * tvstep + wave);
-      const bool act = v < n_tail_units;
-      const int vc = act ? v : 0;
-      const int b = vc / TU;
-      int r = vc - b * TU, g = 0;
-      for (; g < G - 1; ++g) {
-        const int tu = (d->g_pad[g] + 15) >> 4;
-        if (r < tu) break;
-        r -= tu;
-      }
-      const int off = d->g_px_off[g], P = d->g_px_off[g + 1] - off;
-      const int t = L + 16 * r + j;
-      gcnt = act ? 1 : 0;
-      ok = act && t < P;
-      tc = t < P ? t : P - 1;
-#pragma unroll
-      for (int i = 0; i < GB; ++i) { base[i] = B * off + b * P; wg[i] = 0.f; }
-    }
-    bf8 mp[GB][SKM][NS];
-#pragma unroll
-    for (int i = 0; i < GB; ++i) {
-      if (i < gcnt) {
-#pragma unroll
-        for (int s = 0; s < SKM; ++s) {
-          const int grp = 2 * s + (qa >> 1);
-          const __bf16* __restrict__ src = a.m + ((size_t)(base[i] + tc) * kmg + (grp < kmg ? grp : 0)) * PXE + (qa & 1) * 8;
-#pragma unroll
-          for (int pz = 0; pz < NS; ++pz) {
-            mp[i][s][pz] = *(const bf8*)(src + pz * 16);
-            if (grp >= kmg) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) mp[i][s][pz][e] = (__bf16)0.0f;
-            }
-          }
-        }
-      }
-    }
-    f4 aacc[GB][NOA];
-#pragma unroll
-    for (int i = 0; i < GB; ++i)
-#pragma unroll
-      for (int o = 0; o < NOA; ++o) aacc[i][o] = *(const f4*)(a.bc + 16 * o + 4 * qa);
-
-    if (NBUF == 2) dma_chunk(0, 0);
-    for (int hc = 0; hc < a.n_hchunks; ++hc) {
-      if (NBUF == 1) dma_chunk(hc, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                                          // chunk hc has landed; every wave has left chunk hc - 1
-      if (NBUF == 2 && hc + 1 < a.n_hchunks) dma_chunk(hc + 1, (hc + 1) & 1);
-      unsigned wl_off = (unsigned)((NBUF == 2 ? (hc & 1) : 0) * bufsz + lane * 16);
-      // every group re-reads the fragments from LDS: laundering the offset keeps hipcc from holding all 7 group-shared
-      // fragments (84 registers) across the unrolled group loop, which spills
-      auto ldfrag = [&](int f, bf8 (&ap)[NWP]) {
-#pragma unroll
-        for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(wlb + wl_off + (size_t)(f * 3 + pz) * 1024);
-      };
-      if (gcnt > 0) {
-        f4 bo_t[2], res1[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          bo_t[t] = *(const f4*)(bias_l + 16 * (hc * 2 + t) + 4 * qa);
-          res1[t] = *(const f4*)(bias_l + FPc + 16 * (hc * 2 + t) + 4 * qa);
-        }
-        // res1(x) + b, once for all groups of the pass (NS == 2: the accumulator carries sc_res1)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int s = 0; s < SCP; ++s) {
-            bf8 fr[NWP], xp[NS];
-            ldfrag(2 * SKM + t * SCP + s, fr);
-#pragma unroll
-            for (int pz = 0; pz < NS; ++pz) xp[pz] = *(const bf8*)(xl + (size_t)(s * NS + pz) * 1024);
-            res1[t] = chain_bf<NS>(fr, xp, res1[t]);
-          }
-        if (NS == 2) { res1[0] = res1[0] * a.inv_r; res1[1] = res1[1] * a.inv_r; }
-        f4 sacc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int i = 0; i < GB; ++i) {
-          if (i < gcnt) {
-            asm volatile("" : "+v"(wl_off));
-            f4 h[2] = {bo_t[0], bo_t[1]};
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-              for (int s = 0; s < SKM; ++s) {
-                bf8 fr[NWP];
-                ldfrag(t * SKM + s, fr);
-                h[t] = chain_bf<NS>(fr, mp[i][s], h[t]);
-              }
-            // g_g = act(act(W_out1 m_g + b) + res1(x))  (:652-654, then TimesBlock's mid activation :757)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              h[t] = act4<ACT>(NS == 2 ? h[t] * a.inv_o : h[t]) + res1[t];
-              h[t] = act4<ACT>(h[t]);
-              sacc[t] += h[t] * wg[i];
-            }
-            bf8 hp[NS];
-            {
-              const float hv[8] = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
-              split_pieces<NS>(hv, hp);
-            }
-#pragma unroll
-            for (int o = 0; o < NOA; ++o) {
-              bf8 fr[NWP];
-              ldfrag(NL1 + o, fr);
-              aacc[i][o] = chain_bf<NS>(fr, hp, aacc[i][o]);
-            }
-          }
-        }
-        if (!tail_blk) {
-          bf8 sp[NS];
-          const float sv[8] = {sacc[0][0], sacc[0][1], sacc[0][2], sacc[0][3], sacc[1][0], sacc[1][1], sacc[1][2], sacc[1][3]};
-          split_pieces<NS>(sv, sp);
-#pragma unroll
-          for (int o = 0; o < NOR; ++o) {
-            bf8 fr[NWP];
-            ldfrag(NL1 + NOA + o, fr);
-            racc[o] = chain_bf<NS>(fr, sp, racc[o]);
-          }
-        }
-      }
-      if (NBUF == 1) __syncthreads();                           // every wave is done with the single buffer
-    }
-    if (NBUF == 2) __syncthreads();                             // the next pass refills buffer 0
-    // ---- a'_g of this pass
-    if (ok) {
-#pragma unroll
-      for (int i = 0; i < GB; ++i) {
-        if (i < gcnt) {
-#pragma unroll
-          for (int o = 0; o < NOA; ++o)
-            store_px<NS == 2 ? 2 : 3>(a.outA + ((size_t)(base[i] + tc) * (a.AC >> 4) + o) * PXE, qa,
-                                      NS == 2 ? aacc[i][o] * a.inv_a : aacc[i][o]);
-        }
-      }
-    }
-  }
-  if (!ok_m) return;
-  float* __restrict__ rrow = pa.outRs + ((size_t)bm * L + tcm) * a.CP + 4 * qa;
-#pragma unroll
-  for (int o = 0; o < NOR; ++o) *(f4*)(rrow + 16 * o) = NS == 2 ? racc[o] * a.inv_r2 : racc[o];
-}
-
-static const int g_mlp_pos = [] { const char* e = getenv("FTN_MLP_POS"); return e ? atoi(e) : 1; }();      // 0: pixel-major k_mlp_bf_u1
-static const int g_mlp_pos_nwv = [] { const char* e = getenv("FTN_MLP_POS_NWV"); return e ? atoi(e) : 0; }();   // experiment: waves per workgroup
-static const int g_mlp_pos_gb = [] { const char* e = getenv("FTN_MLP_POS_GB"); return e ? atoi(e) : 0; }();     // experiment: groups per pass
-
-template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF>
-static int launch_mlp_pos_t(MlpPosArgs pa, int tail_units_bound, hipStream_t st) {
-  constexpr int NFR = 2 * SKM + 2 * SCP + NOA + NOR;
-  const size_t lds = (size_t)NBUF * NFR * 3 * 1024 + (size_t)pa.c.n_hchunks * 32 * 2 * sizeof(float) + (size_t)NWV * SCP * NS * 1024;
-  if (lds > 160 * 1024) { ftn_set_error("position-major stage C needs %zu B of LDS", lds); return -1; }
-  const long long units = (long long)pa.c.B * ((pa.c.L + 15) / 16);
-  pa.n_main = (int)((units + NWV - 1) / NWV);
-  // the tail pixels are few (pad_g < period): a fixed set of workgroups strides over them
-  const int tail_wg = (tail_units_bound + NWV - 1) / NWV;
-  pa.n_tail = tail_wg < 512 ? tail_wg : 512;
-  auto kfn = k_mlp_pos<ACT, XVEC, NS, SKM, SCP, NOA, NOR, NWV, GB, NBUF>;
-  hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_pos): %s", hipGetErrorString(e)); return (int)e; }
-  hipLaunchKernelGGL(kfn, dim3(pa.n_main + pa.n_tail), dim3(NWV * 64), lds, st, pa);
-  FTN_CHECK_LAUNCH();
-  return 0;
-}
-
-// d_model-64 shape (two K slabs each, 3 + 4 output tiles).  Launch shape: two 4-wave workgroups per CU with a single
-// weight buffer each (a workgroup's exposed refill is covered by its neighbour), or for small batches 2-wave
-// workgroups so that the grid still covers the chip.
-template <int ACT, int NS>
-static int launch_mlp_pos64(const MlpPosArgs& pa, bool xvec, int tail_units_bound, hipStream_t st) {
-  const long long units = (long long)pa.c.B * ((pa.c.L + 15) / 16);
-  const int nwv = g_mlp_pos_nwv ? g_mlp_pos_nwv : (units >= 4096 ? 4 : 2);
-  // groups per pass = what 256 registers hold: 5 with two activation pieces (f16x2) or one (bf16), 4 with three (bf16x3)
-  constexpr int GBD = NS == 3 ? 4 : 5;
-#define FTN_POS_CASE(W, GBV, NB)                                                                                              \
-  if (nwv == W && (g_mlp_pos_gb == 0 || g_mlp_pos_gb == GBV))                                                                \
-    return xvec ? launch_mlp_pos_t<ACT, true, NS, 2, 2, 3, 4, W, GBV, NB>(pa, tail_units_bound, st)                          \
-                : launch_mlp_pos_t<ACT, false, NS, 2, 2, 3, 4, W, GBV, NB>(pa, tail_units_bound, st);
-  FTN_POS_CASE(4, GBD, 1)
-  FTN_POS_CASE(2, GBD, 1)
-  if constexpr (NS == 2) {
-    FTN_POS_CASE(8, GBD, 2)
-    FTN_POS_CASE(4, 4, 1)
-  }
-#undef FTN_POS_CASE
-  ftn_set_error("position-major stage C: no build for FTN_MLP_POS_NWV=%d FTN_MLP_POS_GB=%d", nwv, g_mlp_pos_gb);
-  return -1;
 }
 
 // ---------------------------------------------------------------- stages B / D
@@ -3076,7 +2705,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     const bool r_keeps_x = mlp_bf && g_mlp_u1 && g_r_keeps_x && act_dtype == 0 && (CA + 31) / 32 == 2 && (CP + 31) / 32 == 2 &&
                            n_ot_c == 7 && CA <= 48 && CP <= 64;
     // position-major stage C (k_mlp_pos) for the same shape: res1 / res2 once per window position, R group-summed
-    const bool mlp_pos = mlp_bf && g_mlp_u1 && g_mlp_pos != 0 && act_dtype == 0 && (CA + 31) / 32 == 2 && (CP + 31) / 32 == 2 &&
+    const bool mlp_pos = mlp_bf && g_mlp_u1 && ftn_mlp_pos_enabled() != 0 && act_dtype == 0 && (CA + 31) / 32 == 2 && (CP + 31) / 32 == 2 &&
                          n_ot_c == 7 && CA == 48 && CP == 64;
     if (use_bf) {
       cb.in = (const __bf16*)bufA; cb.bt_L = L; cb.out = buf1; cb.out_p3 = (mlp_bf || mlp_bf128) ? 1 : 0; cb.bias = wb + (h2 ? pl->b_conv1s : pl->b_conv1); cb.desc = desc;
@@ -3156,13 +2785,12 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
       } else if (mlp_pos) {
         MlpPosArgs mp = {};
         mp.c = mb; mp.c.r_keeps_x = 1; mp.wts = wts; mp.outRs = bufR;
+        mp.c.dbg = (g_stamp_which & 2) ? g_stamp_buf : nullptr; mp.c.dbg_cap = g_stamp_cap;
         // units of 16 tail pixels per batch row: sum_g ceil(pad_g / 16) <= (sum_g pad_g + 15 G) / 16, sum_g pad_g <= px_row - L
         const int tail_row = px_row > L ? (px_row - L + 15 * max_groups) / 16 : 0;
         const long long tail_units = (long long)B * tail_row;
         const int tub = tail_units > (1 << 24) ? (1 << 24) : (int)tail_units;
-        if (nsplit == 3) { if ((rc = launch_mlp_pos64<ACT, 3>(mp, xvec, tub, st))) return rc; }
-        else if (nsplit == 2) { if ((rc = launch_mlp_pos64<ACT, 2>(mp, xvec, tub, st))) return rc; }
-        else if ((rc = launch_mlp_pos64<ACT, 1>(mp, xvec, tub, st))) return rc;
+        if ((rc = ftn_launch_mlp_pos64(mp, ACT, nsplit, xvec, tub, st))) return rc;
       } else if (g_mlp_u1 && mb.nsKM == 2 && mb.nsCP == 2 && mb.n_ot == 7) {
         // one 16-pixel unit per wave, four waves per SIMD (see k_mlp_bf_u1)
         if (nsplit == 3) { if ((rc = launch_mlp_bf_u1<ACT, 3, 2, 2, 7>(mb, xvec, Nmax, st))) return rc; }

@@ -212,6 +212,31 @@ def test_awkward_geometries_match_oracle(B, L, C, hyper, periods, engine, ftn, d
     np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL)
 
 
+# ---- position-major stage C (k_mlp_pos): more groups than one pass holds (5 with two activation pieces, 4 with
+#      three), every group padded (tail pixels t >= L, several 16-pixel tail units per row), ragged last unit of a row
+@pytest.mark.parametrize("engine", ["bf16x3", "f16x2", "bf16"])
+@pytest.mark.parametrize("B,L,periods", [
+    (3, 336, [5, 9, 16, 24, 33, 50, 100]),           # 7 groups: two passes; pads 4, 6, 0, 0, 27, 14, 64
+    (2, 150, [70, 7, 11, 13, 17, 19, 23, 29, 31]),   # 9 groups, L % 16 != 0; period 70 pads 60 = four tail units per row
+    (9, 100, [33]),                                  # one group, pad 32: tail units of exactly 16 pixels
+])
+def test_position_major_passes_and_tails(B, L, periods, engine, ftn, dev):
+    case = dict(hyper="pipeline", C=64, seed=23)
+    blk, P, ks, act = _block(ftn, case, dev, engine)
+    rs = np.random.RandomState(8)
+    amps = rs.standard_normal(size=(B, len(periods))).astype(np.float32)
+    object.__setattr__(blk, "period_selector", _Stub(periods, amps))
+    x = torch.from_numpy(ftn.synth.make_input(B, L, 64, seed=10, planted=()))
+    y_ref, aux = orc.timesblock_forward(x, P, ks, act, 0, L, 1, periods=periods, amps=torch.from_numpy(amps))
+    with torch.inference_mode():
+        y = blk(x.to(dev))
+    assert blk._last_backend == "hip" and blk._last_group_count == len(aux.groups.periods)
+    if engine == "bf16":                                        # plain bf16 products: BASELINE configs[2], not an fp32 claim
+        assert float((y.cpu() - y_ref).abs().max()) < 0.05 * float(y_ref.abs().max())
+    else:
+        np.testing.assert_allclose(y.cpu().numpy(), y_ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
 def test_engines_agree_and_plain_bf16_is_close(ftn, dev):
     """f32 and bf16x3 differ at rounding level; plain bf16 (BASELINE configs[2]) is a
     reduced-precision path with its own tolerance."""
