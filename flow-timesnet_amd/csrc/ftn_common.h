@@ -266,6 +266,25 @@ __device__ __forceinline__ void store_h2(__bf16* __restrict__ grp, int q, f4 v) 
   *(u2*)(grp + 16 + 4 * q) = u2{pc[1][0], pc[1][1]};
 }
 
+// ---- fp16 range guard of the f16x2 engine --------------------------------------------------------
+// A value whose magnitude reaches the fp16 maximum (or is not a number) cannot travel as fp16 pieces: the kernels
+// test every value where it is split (x, a, m, a' at their stores; y for NaN / inf at the end - a hidden value g
+// that overflows makes a' non-finite, fp32 accumulation keeps that) and set the caller's flag word; the host then
+// repeats the call on the bf16x3 engine (full fp32 exponent range).  The flag lives in host-visible memory or in
+// device memory; all writers store the same value, so a plain store is enough.
+#define FTN_H2_MAX 65504.0f
+__device__ __forceinline__ bool h2_bad(float v) { return !(fabsf(v) < FTN_H2_MAX); }
+__device__ __forceinline__ bool h2_bad4(f4 v) { return h2_bad(v.x) || h2_bad(v.y) || h2_bad(v.z) || h2_bad(v.w); }
+__device__ __forceinline__ bool not_finite4(f4 v) {
+  return !(fabsf(v.x) <= 3.402823466e38f) || !(fabsf(v.y) <= 3.402823466e38f) || !(fabsf(v.z) <= 3.402823466e38f) ||
+         !(fabsf(v.w) <= 3.402823466e38f);
+}
+// once per wave, at the end of a kernel
+__device__ __forceinline__ void raise_range_flag(int* flag, bool bad) {
+  if (flag != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0)
+    __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Piece-count-generic forms used by the kernels: NS = 3 bf16x3 (P3, 96 B), NS = 2 f16x2 (H2, 64 B),
 // NS = 1 plain bf16 (reads only the hi piece of a P3 record).
 template <int NS> struct PxFmt { static constexpr int BYTES = 96; static constexpr int ELEMS = 48; static constexpr int NW = NS; };

@@ -37,6 +37,7 @@ struct MlpBfArgs {
   // and g = act(acc_r * inv_r);  a' = acc * inv_a (tiles < n_oa),  r = acc * inv_r2 - x.  All 1 otherwise.
   float inv_o, sc_r, inv_r, inv_a, inv_r2;
   int r_keeps_x;         // 1: outR = res2(g) + b (x NOT subtracted: k_out takes it out once, OutArgs.r_keeps_x)
+  int* range_flag;       // f16x2 engine: set when x or a' leaves the fp16 range (ftn_common.h); may be null
   unsigned long long* dbg; size_t dbg_cap;
 };
 

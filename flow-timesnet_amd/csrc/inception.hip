@@ -60,6 +60,7 @@ struct PwArgs {
   // stage A also publishes the sanitised descriptor copy every later launch reads (guard_desc below); it does
   // not need the descriptor itself, so this costs no extra launch
   const FtnDesc* guard_src; FtnDesc* guard_dst; int guard_groups, guard_px;
+  int* range_flag;       // EPI 3 (f16x2 pieces): set when an output leaves the fp16 range; may be null
 };
 
 // Copies the caller's descriptor to the head of the workspace; a descriptor that exceeds the bounds the
@@ -190,6 +191,7 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bid) {
     }
   }
   const int KIN = a.KIN;
+  bool range_bad = false;
   for (int og = 0; og < a.n_ot; og += 4) {
     f4 acc[4][NPXU];
 #pragma unroll
@@ -229,6 +231,7 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bid) {
             *(f4*)op = acc[o][u];
           } else if (EPI == 2 || EPI == 3) {   // bf16x3 (P3) / f16x2 (H2) pieces: input of the split conv engines
             constexpr int NSP = EPI == 3 ? 2 : 3;
+            if (EPI == 3) range_bad |= h2_bad4(acc[o][u]);
             store_px<NSP>((__bf16*)a.out + ((size_t)px[u].n * (a.OUTC >> 4) + (og + o)) * PxFmt<NSP>::ELEMS, q, acc[o][u]);
           } else if (EPI == 4) {
             *(f4*)op = acc[o][u] - load_x4<XVEC>(px[u].xrow, ch, a.C);
@@ -241,6 +244,7 @@ __device__ __forceinline__ void pw_body(const PwArgs& a, const int bid) {
       }
     }
   }
+  if (EPI == 3) raise_range_flag(a.range_flag, range_bad);
 }
 
 template <int ACT, int XIN, bool XVEC, int EPI>
@@ -604,6 +608,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
   constexpr int NWP = PxFmt<NS>::NW;                          // weight pieces per fragment
   constexpr int PXE = PxFmt<NS>::ELEMS;                       // 16-bit elements per pixel and 16-channel group
   // B operands that do not depend on the hidden chunk
+  bool range_bad = false;                                       // f16x2: a value left the fp16 range (ftn_common.h)
   bf8 mp[2][NPX][NS], xp[2][NPX][NS];
   f4 xraw[2][NPX][2];
 #pragma unroll
@@ -642,6 +647,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
       float xv[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { xv[e] = xraw[s][u][0][e]; xv[4 + e] = xraw[s][u][1][e]; }
+      if (NS == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) range_bad |= h2_bad(xv[e]);
+      }
       split_pieces<NS>(xv, xp[s][u]);
     }
   }
@@ -777,7 +786,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
     if (hc == 1) stamp(a.dbg, a.dbg_cap, blockIdx.x, 6);
   }
   stamp(a.dbg, a.dbg_cap, blockIdx.x, 3);
-  if (!active) return;
+  if (!active) { if (NS == 2) raise_range_flag(a.range_flag, range_bad); return; }
 #pragma unroll
   for (int o = 0; o < OTM; ++o) {
     if (EXACT || o < n_ot) {
@@ -785,8 +794,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
       for (int u = 0; u < NPX; ++u) {
         if (!px[u].ok) continue;
         if (o < a.n_oa) {
-          store_px<NS == 2 ? 2 : 3>(a.outA + ((size_t)px[u].n * (a.AC >> 4) + o) * PXE, qa,
-                                    NS == 2 ? oacc[o][u] * a.inv_a : oacc[o][u]);
+          const f4 av = NS == 2 ? oacc[o][u] * a.inv_a : oacc[o][u];
+          if (NS == 2) range_bad |= h2_bad4(av);
+          store_px<NS == 2 ? 2 : 3>(a.outA + ((size_t)px[u].n * (a.AC >> 4) + o) * PXE, qa, av);
         } else {
           const int ch = 16 * (o - a.n_oa) + 4 * qa;
           const f4 rv = NS == 2 ? oacc[o][u] * a.inv_r2 : oacc[o][u];
@@ -795,6 +805,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_mlp_bf(MlpBfArgs a) {
       }
     }
   }
+  if (NS == 2) raise_range_flag(a.range_flag, range_bad);
 }
 
 // ---------------------------------------------------------------- stage C, bf16x3 engine, d_model 128
@@ -861,6 +872,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
   const int kmg = a.KM >> 4;
   constexpr int NWP = PxFmt<NS>::NW;
   constexpr int PXE = PxFmt<NS>::ELEMS;
+  bool range_bad = false;                                       // f16x2: a value left the fp16 range (ftn_common.h)
   bf8 mp[SKM][NS], xp[SCP][NS];
   f4 xraw[SCP][2];
 #pragma unroll
@@ -898,6 +910,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
     float xv[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { xv[e] = xraw[s][0][e]; xv[4 + e] = xraw[s][1][e]; }
+    if (NS == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) range_bad |= h2_bad(xv[e]);
+    }
     split_pieces<NS>(xv, xp[s]);
   }
   f4 oacc[OTM];
@@ -1013,6 +1029,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 16 ? 1 : (NWV == 4 ? 3 : 2)) void 
       __syncthreads();
     }
   }
+  if (active && px.ok && NS == 2) {
+#pragma unroll
+    for (int o = 0; o < OTM; ++o)
+      if (o < a.n_oa) range_bad |= h2_bad4(oacc[o] * a.inv_a);
+  }
+  if (NS == 2) raise_range_flag(a.range_flag, range_bad);
   if (!active || !px.ok) return;
 #pragma unroll
   for (int o = 0; o < OTM; ++o) {
@@ -1325,6 +1347,7 @@ struct ConvBfArgs {
   int bt_L;              // as ConvArgs.bt_L: > 0 = input rows per window position + one pad row
   float inv[FTN_MAXBR];  // f16x2: 2^-s of the branch's prescaled weights (applied to the accumulators)
   int wg_off[FTN_MAXBR + 1];   // k_conv_bf_fast: workgroups [wg_off[k], wg_off[k+1]) serve branch k
+  int* range_flag;       // f16x2 piece output (out_p3): set when an output leaves the fp16 range; may be null
   unsigned long long* dbg; size_t dbg_cap;
 };
 
@@ -1344,6 +1367,7 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
   constexpr int PXE = PxFmt<NS>::ELEMS;                       // 16-bit elements per pixel and 16-channel group in memory
   const FtnDesc* __restrict__ d = a.desc;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
+  bool range_bad = false;                                       // f16x2: an output left the fp16 range
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int zb = blockIdx.z / a.nchunk, chunk = blockIdx.z - zb * a.nchunk;
   const int br = a.order[zb];
@@ -1546,6 +1570,7 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
             if (u < nu && pok[u]) {
               const int ch = br * a.out_stride_br + 16 * (co0 + o);
               const f4 v = NS == 2 ? acc[o][u] * inv : acc[o][u];
+              if (NS == 2 && a.out_p3) range_bad |= h2_bad4(v);
               if (a.out_p3) store_px<NS == 2 ? 2 : 3>((__bf16*)a.out + ((nimg + oidx[u]) * (a.OUTC >> 4) + (ch >> 4)) * PXE, lane >> 4, v);
               else *(f4*)((float*)a.out + (nimg + oidx[u]) * a.OUTC + ch + 4 * (lane >> 4)) = v;
             }
@@ -1556,6 +1581,7 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
   }
   stamp(a.dbg, a.dbg_cap, wgid, 3);
   if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) a.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+  if (NS == 2) raise_range_flag(a.range_flag, range_bad);
 }
 
 // ---------------------------------------------------------------- stages B / D, split engines, fast path
@@ -1675,6 +1701,7 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   constexpr int plane = CBF_FAST_PLANE;
   const FtnDesc* __restrict__ d = a.desc;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
+  bool range_bad = false;                                       // f16x2: an output left the fp16 range
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   int br = 0;
   while (br + 1 < a.nbr && (int)blockIdx.x >= a.wg_off[br + 1]) ++br;
@@ -1841,7 +1868,11 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
         __bf16* __restrict__ ob = (__bf16*)a.out + nimg * (size_t)(a.OUTC >> 4) * PXE;
 #pragma unroll
         for (int u = 0; u < CBF_NU; ++u)
-          if (u < nu && pok[u]) store_px<NS == 2 ? 2 : 3>(ob + ooff[u], qa, NS == 2 ? acc[u] * inv : acc[u]);
+          if (u < nu && pok[u]) {
+            const f4 v = NS == 2 ? acc[u] * inv : acc[u];
+            if (NS == 2) range_bad |= h2_bad4(v);
+            store_px<NS == 2 ? 2 : 3>(ob + ooff[u], qa, v);
+          }
       } else {
         float* __restrict__ ob = (float*)a.out + nimg * (size_t)a.OUTC;
 #pragma unroll
@@ -1852,6 +1883,7 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   }
   stamp(a.dbg, a.dbg_cap, wgid, 3);
   if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) a.dbg[wgid * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+  if (NS == 2) raise_range_flag(a.range_flag, range_bad);
 }
 
 // ---------------------------------------------------------------- small elementwise stages
@@ -1895,6 +1927,7 @@ struct OutArgs {
                          // for half inputs every per-group delta is rounded, so x must come off before the weighting
   int act_dtype;         // 1 bf16 / 2 fp16 input: the reference rounds every per-group delta, each weighted
                          // term, their sum and x + sum to the input dtype (:1068-1069, :1092, :818); 0 = fp32
+  int* range_flag;       // f16x2 engine: set when an output value is not finite (ftn_common.h); may be null
   int r_summed;          // position-major stage C (k_mlp_pos): R is ONE [B*L][CP] tensor that already holds
                          // sum_g w_g (res2(g_g) + b) per window position: y = x + (sum_g w_g e_g + R - (sum_g w_g) x)
 };
@@ -2107,6 +2140,15 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
       }
     }
     if (ln) ln_tiles<4, NPX>(yacc, n_ot, a.C, q, a.ln_g, a.ln_b, a.ln_eps);
+    if (a.range_flag != nullptr) {
+      bool bad = false;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int u = 0; u < NPX; ++u)
+          if (o < n_ot && ok[u]) bad |= not_finite4(yacc[o][u]);
+      raise_range_flag(a.range_flag, bad);
+    }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       if (o < n_ot) {
@@ -2188,6 +2230,15 @@ __global__ __launch_bounds__(256, NPX == 1 ? 3 : 2) void k_out(OutArgs a) {
           }
         }
       }
+    }
+    if (a.range_flag != nullptr) {
+      bool bad = false;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int u = 0; u < NPX; ++u)
+          if (og + o < n_ot && ok[u]) bad |= not_finite4(yacc[o][u]);
+      raise_range_flag(a.range_flag, bad);
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -2649,7 +2700,7 @@ static int launch_mlp_bf(const MlpBfArgs& ma, bool xvec, long long Nmax, hipStre
 template <int ACT>
 static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, const float* wb, const FtnDesc* desc_in,
                      const float* wts, int max_groups, int px_bound, char* ws, hipStream_t st, const float* ln_g,
-                     const float* ln_b, float ln_eps, int act_dtype, int flags) {
+                     const float* ln_b, float ln_eps, int act_dtype, int flags, int* range_flag) {
   const WsLayout wl = ws_layout(pl, B, L, max_groups, px_bound);
   const int px_row = worst_px_per_row(L, max_groups, px_bound);
   const FtnDesc* desc = (const FtnDesc*)ws;     // sanitised copy, written by the first launch (stage A)
@@ -2686,6 +2737,8 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     pa.x = x; pa.W = wb + pl->w_in1; pa.bias = wb + pl->b_in1; pa.out = bufA; pa.desc = desc;
     pa.B = B; pa.L = L; pa.C = C; pa.KIN = CP; pa.n_ot = CA / 16; pa.OUTC = CA;
     pa.guard_src = desc_in; pa.guard_dst = (FtnDesc*)ws; pa.guard_groups = max_groups; pa.guard_px = px_row;
+    if (!h2) range_flag = nullptr;                              // only the f16x2 engine has a range to guard
+    pa.range_flag = range_flag;
     if (flags & FTN_FWD_STAGE_A_DONE) { /* ftn_period_finalize_stage_a ran stage A and published the descriptor copy */ }
     else if (use_bf && h2) { if ((rc = launch_pw<ACT, 1, 3>(pa, xvec, nblk_pw, st))) return rc; }
     else if (use_bf) { if ((rc = launch_pw<ACT, 1, 2>(pa, xvec, nblk_pw, st))) return rc; }
@@ -2708,6 +2761,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     const bool mlp_pos = mlp_bf && g_mlp_u1 && ftn_mlp_pos_enabled() != 0 && act_dtype == 0 && (CA + 31) / 32 == 2 && (CP + 31) / 32 == 2 &&
                          n_ot_c == 7 && CA == 48 && CP == 64;
     if (use_bf) {
+      cb.range_flag = range_flag;
       cb.in = (const __bf16*)bufA; cb.bt_L = L; cb.out = buf1; cb.out_p3 = (mlp_bf || mlp_bf128) ? 1 : 0; cb.bias = wb + (h2 ? pl->b_conv1s : pl->b_conv1); cb.desc = desc;
       cb.B = B; cb.INC = CA; cb.OUTC = CA; cb.nbr = pl->nbr; cb.cin = pl->MP; cb.cout = pl->MP;
       cb.in_stride_br = pl->MP / 16; cb.out_stride_br = pl->MP;
@@ -2773,6 +2827,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
       mb.inv_o = h2 ? 1.0f / pl->sc_out1 : 1.0f; mb.sc_r = h2 ? pl->sc_res1 : 1.0f; mb.inv_r = h2 ? 1.0f / pl->sc_res1 : 1.0f;
       mb.inv_a = h2 ? 1.0f / pl->sc_a2 : 1.0f; mb.inv_r2 = h2 ? 1.0f / pl->sc_r2 : 1.0f;
       mb.r_keeps_x = r_keeps_x ? 1 : 0;
+      mb.range_flag = range_flag;
       mb.outA = (__bf16*)buf0; mb.outR = bufR; mb.desc = desc;
       mb.B = B; mb.L = L; mb.C = C; mb.CP = CP; mb.FP = FP; mb.KM = CA; mb.AC = CA;
       mb.nsKM = (CA + 31) / 32; mb.nsCP = (CP + 31) / 32;
@@ -2816,6 +2871,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     oa.desc = desc; oa.B = B; oa.L = L; oa.C = C; oa.CP = CP; oa.KM = CA; oa.act_dtype = act_dtype;
     oa.r_keeps_x = (r_keeps_x || mlp_pos) ? 1 : 0;
     oa.r_summed = mlp_pos ? 1 : 0;
+    oa.range_flag = range_flag;
     const bool fast = CA <= 48 && CP <= 64;
     if (fast) { oa.ln_g = ln_g; oa.ln_b = ln_b; oa.ln_eps = ln_eps; ln_g = nullptr; }   // fused epilogue
     // FAST path: 16 pixels per wave (3 waves/SIMD; with 32 the kernel needs > 256 registers -> 1 wave/SIMD)
@@ -2882,7 +2938,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
 static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev, int max_groups,
                            int px_bound, void* ws_dev, size_t ws_bytes, void* stream, const float* ln_g, const float* ln_b,
-                           float ln_eps, int act_dtype, int flags) {
+                           float ln_eps, int act_dtype, int flags, int* range_flag) {
   FTN_CHECK_ARG(x_dev && y_dev && plan && wblob_dev && desc_dev && weights_dev && ws_dev,
                 "ftn_timesblock_forward: null pointer");
   FTN_CHECK_ARG(B >= 1 && B <= 65535 && L >= 2, "ftn_timesblock_forward: bad shape B=%d L=%d", B, L);
@@ -2905,9 +2961,9 @@ static int forward_checked(const float* x_dev, float* y_dev, int B, int L, const
                 "ftn_timesblock_forward: workspace/weights must be 256/16-byte aligned");
   if (plan->act == 1)
     return forward_t<1>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, (char*)ws_dev,
-                        (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype, flags);
+                        (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype, flags, range_flag);
   return forward_t<0>(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, (char*)ws_dev,
-                      (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype, flags);
+                      (hipStream_t)stream, ln_g, ln_b, ln_eps, act_dtype, flags, range_flag);
 }
 
 // S3-S5 of the selector and stage A of the block in ONE launch (k_finalize_pw): see flowtimes.h
@@ -2933,7 +2989,7 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
                                            int max_unique, float log_base, FtnDesc* desc_dev, float* amps_dev,
                                            float* weights_dev, const float* x_dev, const FtnPlan* plan,
                                            const float* wblob_dev, int max_groups, int px_bound, void* ws_dev,
-                                           size_t ws_bytes, void* stream) {
+                                           size_t ws_bytes, void* stream, int* range_flag_dev) {
   // psum_dev == NULL: stage A only;  x_dev == NULL: finalize + descriptor copy only (stage A is in the workspace)
   const bool do_fin = psum_dev != nullptr, do_a = x_dev != nullptr;
   FTN_CHECK_ARG(do_fin || do_a, "ftn_period_finalize_stage_a: nothing to do (psum and x both null)");
@@ -2971,6 +3027,7 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
   pa.desc = nullptr; pa.B = B; pa.L = L; pa.C = plan->C; pa.KIN = plan->CP; pa.n_ot = CA / 16; pa.OUTC = CA;
   pa.guard_src = desc_dev; pa.guard_dst = (FtnDesc*)ws_dev; pa.guard_groups = max_groups;
   pa.guard_px = worst_px_per_row(L, max_groups, px_bound);
+  pa.range_flag = epi == 3 ? range_flag_dev : nullptr;
   const bool xvec = (plan->C % 4 == 0) && (((uintptr_t)x_dev & 15) == 0);
   const int nblk_pw = (int)(((long long)B * L + 1 + 16 * NPXU * 4 - 1) / (16 * NPXU * 4));
   const int part = do_fin && do_a ? 0 : (do_a ? 1 : 2);
@@ -2981,19 +3038,19 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
 extern "C" int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                       const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
                                       int max_groups, int px_bound, int act_dtype, int flags, void* ws_dev,
-                                      size_t ws_bytes, void* stream) {
+                                      size_t ws_bytes, void* stream, int* range_flag_dev) {
   return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, ws_dev, ws_bytes,
-                         stream, nullptr, nullptr, 0.f, act_dtype, flags);
+                         stream, nullptr, nullptr, 0.f, act_dtype, flags, range_flag_dev);
 }
 
 extern "C" int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
                                            int max_groups, int px_bound, int flags, const float* ln_gamma_dev,
                                            const float* ln_beta_dev, float ln_eps, void* ws_dev, size_t ws_bytes,
-                                           void* stream) {
+                                           void* stream, int* range_flag_dev) {
   FTN_CHECK_ARG(ln_gamma_dev && ln_beta_dev && ln_eps >= 0.f, "ftn_timesblock_forward_norm: LayerNorm parameters");
   return forward_checked(x_dev, y_dev, B, L, plan, wblob_dev, desc_dev, weights_dev, max_groups, px_bound, ws_dev,
-                         ws_bytes, stream, ln_gamma_dev, ln_beta_dev, ln_eps, 0, flags);
+                         ws_bytes, stream, ln_gamma_dev, ln_beta_dev, ln_eps, 0, flags, range_flag_dev);
 }
 
 extern "C" int ftn_residual_layernorm(const float* x_dev, const float* new_dev, float* out_dev, long long rows, int C,

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
   // a chunk reads its 2 x 2 bias tiles straight from L2 while it waits for its weights.
   const int kmg = a.KM >> 4;
   char* __restrict__ xl = wlb + (size_t)NBUF * bufsz + (size_t)wave * (SCP * NS * 1024) + lane * 16;
+  bool range_bad = false;                                       // f16x2: a value left the fp16 range (ftn_common.h)
   f4 xr[SCP][2];
   {
     const float* __restrict__ xrow = a.x + ((size_t)bm * L + tcm) * a.C;      // a real row even for idle waves (masked below)
@@ -87,6 +88,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
     float xv[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { xv[e] = active_m ? xr[s][0][e] : 0.f; xv[4 + e] = active_m ? xr[s][1][e] : 0.f; }
+    if (NS == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) range_bad |= h2_bad(xv[e]);
+    }
     bf8 xp[NS];
     split_pieces<NS>(xv, xp);
 #pragma unroll
@@ -268,14 +273,17 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
       for (int i = 0; i < GB; ++i) {
         if (i < gcnt) {
 #pragma unroll
-          for (int o = 0; o < NOA; ++o)
-            store_px<NS == 2 ? 2 : 3>(a.outA + ((size_t)(base[i] + tc) * (a.AC >> 4) + o) * PXE, qa,
-                                      NS == 2 ? aacc[i][o] * a.inv_a : aacc[i][o]);
+          for (int o = 0; o < NOA; ++o) {
+            const f4 av = NS == 2 ? aacc[i][o] * a.inv_a : aacc[i][o];
+            if (NS == 2) range_bad |= h2_bad4(av);
+            store_px<NS == 2 ? 2 : 3>(a.outA + ((size_t)(base[i] + tc) * (a.AC >> 4) + o) * PXE, qa, av);
+          }
         }
       }
     }
   }
   stamp(a.dbg, a.dbg_cap, blockIdx.x, 7);
+  if (NS == 2) raise_range_flag(a.range_flag, range_bad);
   if (!ok_m) return;
   float* __restrict__ rrow = pa.outRs + ((size_t)bm * L + tcm) * a.CP + 4 * qa;
 #pragma unroll

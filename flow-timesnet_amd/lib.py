@@ -13,7 +13,7 @@ from typing import Optional
 
 FTN_KMAX = 16
 FTN_MAXBR = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libflowtimes_hip.so"
@@ -98,12 +98,12 @@ _SIGNATURES = {
     "ftn_selector_px_bound": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "ftn_timesblock_workspace_bytes": (C.c_size_t, [C.POINTER(FtnPlan), C.c_int, C.c_int, C.c_int, C.c_int]),
     "ftn_timesblock_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FtnPlan), _P, _P, _P, C.c_int, C.c_int,
-                                         C.c_int, C.c_int, _P, C.c_size_t, _P]),
+                                         C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
     "ftn_timesblock_forward_norm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FtnPlan), _P, _P, _P, C.c_int,
-                                              C.c_int, C.c_int, _P, _P, C.c_float, _P, C.c_size_t, _P]),
+                                              C.c_int, C.c_int, _P, _P, C.c_float, _P, C.c_size_t, _P, _P]),
     "ftn_period_finalize_stage_a": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, C.POINTER(FtnPlan), _P,
-                                              C.c_int, C.c_int, _P, C.c_size_t, _P]),
+                                              C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
     "ftn_residual_layernorm": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int, _P, _P, C.c_float, _P]),
     "ftn_head_forward": (C.c_int, [_P, C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_longlong,
                                    C.c_int, _P, C.c_longlong, _P, C.c_float, _P, _P, _P, _P]),

@@ -115,8 +115,8 @@ class FFTPeriodSelector(nn.Module):
         """Run S1-S5 on the device; returns a ``runtime.Selection`` (or ``None`` when
         the selector is degenerate, reference :89-90,140-142).  ``act_dtype`` (default: ``x.dtype``) is the
         caller's activation dtype: for bf16 / fp16 the reference's roundings of scores, amplitudes and
-        softmax weights are applied (:124-159, :1000-1009).  ``stage_a=(plan, wblob)`` of the TimesBlock that
-        will consume the selection lets its first stage share the finalize launch (``runtime.finalize``)."""
+        softmax weights are applied (:124-159, :1000-1009).  ``stage_a=(plan, wblob[, range_flag])`` of the TimesBlock
+        that will consume the selection lets its first stage share the finalize launch (``runtime.finalize``)."""
         from .. import runtime
 
         if x.ndim != 3:
@@ -145,18 +145,20 @@ class FFTPeriodSelector(nn.Module):
             overlap = stage_a is not None and runtime.fuse_stage_a(stage_a[0])
             if dist.get_backend(self.shard_group) == "gloo":      # CPU-side rehearsal of the exchange
                 if overlap:
-                    pre = runtime.stage_a_only(xf, stage_a[0], stage_a[1], self.k, self.pmax, self.min_period_threshold)
+                    pre = runtime.stage_a_only(xf, stage_a[0], stage_a[1], self.k, self.pmax, self.min_period_threshold,
+                                               stage_a[2] if len(stage_a) > 2 else None)
                 dist.all_gather(list(parts.unbind(0)), psum, group=self.shard_group)
             else:                                                  # RCCL
                 work = dist.all_gather_into_tensor(parts, psum, group=self.shard_group, async_op=True)
                 if overlap:                                        # enqueued behind the spectrum, beside the exchange
-                    pre = runtime.stage_a_only(xf, stage_a[0], stage_a[1], self.k, self.pmax, self.min_period_threshold)
+                    pre = runtime.stage_a_only(xf, stage_a[0], stage_a[1], self.k, self.pmax, self.min_period_threshold,
+                                               stage_a[2] if len(stage_a) > 2 else None)
                 work.wait()                                        # the compute stream waits; the host does not
             b_total = B * world          # equal shards (no host sync to learn otherwise)
             psum = parts
         sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold, adt,
                                max_unique or 0, log_base or 0.0,
-                               stage_a=None if stage_a is None else (xf, stage_a[0], stage_a[1]), pre=pre)
+                               stage_a=None if stage_a is None else (xf,) + tuple(stage_a), pre=pre)
         self._pending = sel
         return sel
 
@@ -307,9 +309,18 @@ class TimesBlock(nn.Module):
         self._lazy_sel = None
         self._pack_key = None
         self._pack = None
-        # conv arithmetic of the HIP backend: None = pack.default_engine() ("bf16x3" unless
-        # FLOWTIMES_ENGINE says otherwise); "f32" = exact fp32 MFMA; "bf16" = plain bf16
+        self._packs = {}
+        # conv arithmetic of the HIP backend: None = pack.default_engine() ("f16x2" unless FLOWTIMES_ENGINE says
+        # otherwise); "bf16x3" = three bf16 pieces, full fp32 exponent range; "f32" = exact fp32 MFMA; "bf16" = plain bf16
         self.engine: Optional[str] = None
+        # f16x2 range guard (include/flowtimes.h, ABI 9): the kernels flag values that do not fit fp16 pieces; the
+        # flag of a call is looked at once its completion event has fired - at the next call of this block, by
+        # check_range(), or when _last_engine is read - and a flagged call is repeated on bf16x3 INTO THE SAME output
+        self._range_slots: list = []          # free (flag, event) pairs
+        self._range_pending: list = []        # calls in flight: (flag, event, x, y, post_norm)
+        self._range_dev_flag = None           # device-memory flag used while a HIP graph is being captured
+        self._last_engine_used: Optional[str] = None
+        self._range_fallbacks = 0
 
     # ---- construction ------------------------------------------------------
     def _build_layers(self, channels: int, device: torch.device, dtype: torch.dtype) -> None:
@@ -355,20 +366,23 @@ class TimesBlock(nn.Module):
     del _counter
 
     # ---- packed weights for the HIP kernels ---------------------------------
-    def _packed(self, device: torch.device):
+    def _packed(self, device: torch.device, engine: Optional[str] = None):
         from .. import pack
 
         params = list(self.inception.parameters())
-        engine = getattr(self, "engine", None) or pack.default_engine()
+        engine = engine or getattr(self, "engine", None) or pack.default_engine()
         # inference tensors (lazy build under torch.inference_mode) carry no version counter
-        key = (str(device), engine) + tuple(
+        key = (str(device),) + tuple(
             (p.data_ptr(), -1 if p.is_inference() else p._version) for p in params)
-        if self._pack_key != key:
+        if self._pack_key != key:                               # new weights / device: every engine's blob is stale
+            self._packs = {}
+            self._pack_key = key
+        if engine not in self._packs:
             sd = {k: v.detach().float().cpu().numpy() for k, v in self.inception.state_dict().items()}
             blob, plan = pack.pack_inception(sd, self.d_model, self.d_ff, self._kernel_spec,
                                              self.bottleneck_ratio, self._activation_name, engine)
-            self._pack = (torch.from_numpy(blob).to(device), plan)
-            self._pack_key = key
+            self._packs[engine] = (torch.from_numpy(blob).to(device), plan)
+        self._pack = self._packs[engine]
         return self._pack
 
     def invalidate_pack(self) -> None:
@@ -379,6 +393,52 @@ class TimesBlock(nn.Module):
         were captured with (``graph.GraphedForward`` holds a reference)."""
         self._pack_key = None
         self._pack = None
+        self._packs = {}
+
+    # ---- f16x2 range guard -------------------------------------------------------
+    def _engine_name(self) -> str:
+        from .. import pack
+
+        return getattr(self, "engine", None) or pack.default_engine()
+
+    def _resolve_range(self, block: bool) -> None:
+        """Look at the range flags of finished f16x2 calls (all pending calls when ``block``); a flagged call is
+        repeated on the bf16x3 engine into the output tensor it returned."""
+        while self._range_pending:
+            flag, ev, x, y, post_norm = self._range_pending[0]
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            self._range_pending.pop(0)
+            tripped = int(flag.item()) != 0                      # pinned host word: a plain read
+            if tripped:
+                flag.zero_()
+            self._range_slots.append((flag, ev))
+            self._last_engine_used = "f16x2"
+            if tripped:
+                import warnings
+
+                warnings.warn("TimesBlock: a value left the fp16 range of engine f16x2 (|v| >= 65504 or not finite); "
+                              "the call was repeated on engine bf16x3", RuntimeWarning, stacklevel=3)
+                self._range_fallbacks += 1
+                y2 = self._forward_hip(x, post_norm, engine="bf16x3")
+                y.copy_(y2 if y2.dtype == y.dtype else y2.to(y.dtype))
+                self._last_engine_used = "bf16x3"
+
+    def check_range(self) -> Optional[str]:
+        """Wait for this block's outstanding HIP calls and repair any whose values left the f16x2 engine's fp16
+        range (see ``_resolve_range``); returns the engine the last call finally ran on."""
+        self._resolve_range(block=True)
+        flag = self._range_dev_flag
+        if flag is not None and int(flag.item()) != 0:           # set during a captured / deferred forward
+            raise FloatingPointError("TimesBlock: a value left the fp16 range of engine f16x2 inside a captured "
+                                     "forward; set block.engine = 'bf16x3' and capture again")
+        return self._last_engine_used
+
+    @property
+    def _last_engine(self) -> Optional[str]:
+        return self.check_range()
 
     # ---- forward ---------------------------------------------------------------
     def forward(self, x: torch.Tensor, post_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
@@ -400,7 +460,7 @@ class TimesBlock(nn.Module):
                 raise ValueError("Number of channels changed between calls")
 
         use_hip = (self._standard_inception() and not (self.training and self._dropout > 0.0)
-                   and _hip_eligible(x, self.inception))
+                   and _hip_eligible(x, self.inception) and self._within_native_limits())
         fused = (post_norm is not None and use_hip and _affine_layernorm(post_norm, x.size(-1))
                  and _hip_eligible(x, post_norm) and x.dtype == torch.float32)
         if not use_hip:
@@ -414,9 +474,36 @@ class TimesBlock(nn.Module):
             new = _layer_norm_fp32(post_norm, x + (new - x))
         return new
 
+    def _within_native_limits(self) -> bool:
+        """The HIP kernels hold at most FTN_KMAX period candidates and FTN_MAXBR kernels per InceptionBlock; the
+        reference has no such limits (:55-62, :622-633), so anything beyond them runs on the torch backend."""
+        from ..lib import FTN_MAXBR
+
+        sel = self.period_selector
+        k = getattr(sel, "k", None) if type(sel) is FFTPeriodSelector else None
+        return len(self._kernel_spec) <= FTN_MAXBR and (k is None or int(k) <= FTN_KMAX)
+
     # ---- HIP backend -----------------------------------------------------------
-    def _forward_hip(self, x: torch.Tensor, post_norm: Optional[nn.LayerNorm] = None) -> torch.Tensor:
+    def _forward_hip(self, x: torch.Tensor, post_norm: Optional[nn.LayerNorm] = None,
+                     engine: Optional[str] = None) -> torch.Tensor:
         from .. import lib, runtime
+
+        engine = engine or self._engine_name()
+        guarded = engine == "f16x2" and os.getenv("FTN_RANGE_GUARD", "1") != "0"
+        range_flag = slot_ev = None
+        if guarded:
+            if torch.cuda.is_current_stream_capturing():
+                # a captured forward cannot record host events: it sets a device word (zeroed by a captured fill at
+                # every replay) that check_range() / TimesNet.check_outputs() read after the replay
+                self._range_dev_flag = range_flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+            else:
+                self._range_dev_flag = None
+                self._resolve_range(block=False)
+                if len(self._range_pending) >= 8:              # the host runs far ahead: wait for the oldest call only
+                    self._range_pending[0][1].synchronize()
+                    self._resolve_range(block=False)
+                range_flag, slot_ev = self._range_slots.pop() if self._range_slots else (
+                    runtime.new_range_flag(x.device), torch.cuda.Event())
 
         norm = None
         if post_norm is not None:
@@ -425,6 +512,8 @@ class TimesBlock(nn.Module):
 
         def unchanged():
             # the reference returns x itself (:796-797); the shell then normalises x + (x - x)
+            if slot_ev is not None:
+                self._range_slots.append((range_flag, slot_ev))
             if norm is None:
                 return x
             xc = x.detach().float().contiguous()
@@ -446,10 +535,10 @@ class TimesBlock(nn.Module):
         adt = runtime.ACT_DTYPE.get(x.dtype, 0)
         if adt != 0:
             norm = None                        # half inputs: the shell's LayerNorm runs outside (see forward)
-        wblob, plan = self._packed(x.device)
+        wblob, plan = self._packed(x.device, engine)
         if native:
             sel = sel_mod.select_device(xf, act_dtype=x.dtype, max_unique=max_unique, log_base=log_base,
-                                        stage_a=(plan, wblob))
+                                        stage_a=(plan, wblob, range_flag))
             if sel is None:                                            # reference :796-797
                 self._last_raw_period_count = self._last_valid_period_count = self._last_group_count = 0
                 return unchanged()
@@ -478,7 +567,14 @@ class TimesBlock(nn.Module):
             if int(dh.n_groups) != grp.periods.numel():
                 raise RuntimeError("host grouping and descriptor disagree")
             sel = runtime.selection_from_host(dh, w, x.device)
-        y = runtime.timesblock_forward(xf, plan, wblob, sel, norm, adt)
+        y = runtime.timesblock_forward(xf, plan, wblob, sel, norm, adt, range_flag)
+        if y.dtype != x.dtype:
+            y = y.to(x.dtype)
+        if slot_ev is not None:
+            slot_ev.record()
+            self._range_pending.append((range_flag, slot_ev, x, y, post_norm))
+        elif not guarded:
+            self._last_engine_used = engine
         if _env_on("TIMESBLOCK_VEC_DISABLE"):
             # same kernels either way (the two reference paths are the same math, :866-953);
             # only the counters differ.  Reading the group count synchronises, as the reference does.
@@ -486,7 +582,7 @@ class TimesBlock(nn.Module):
         else:
             self._vec_calls += 1
             self._last_loop_iterations = 0
-        return y if y.dtype == x.dtype else y.to(x.dtype)
+        return y
 
     # ---- torch backend (generic: any inception module, autograd, CPU) ----------
     def _forward_torch(self, x: torch.Tensor) -> torch.Tensor:

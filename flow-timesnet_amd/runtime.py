@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, Tuple
+from typing import Optional, Dict, Tuple
 
 import torch
 
@@ -24,6 +24,10 @@ def _stream(device: torch.device) -> int:
 
 def _ptr(t: torch.Tensor) -> int:
     return t.data_ptr()
+
+
+def _ptr_or_null(t):
+    return None if t is None else t.data_ptr()
 
 
 class DeviceState:
@@ -112,12 +116,23 @@ def _selector_bounds(lib, L: int, k: int, pmax: int, min_thr: int) -> Tuple[int,
     return max(1, int(mg.value)), int(pxb)
 
 
+def new_range_flag(device: torch.device) -> torch.Tensor:
+    """One int32 the f16x2 kernels set when a value leaves the fp16 range (``include/flowtimes.h``, ABI 9).  By default
+    it lives in pinned host memory, which the device writes directly (zero-copy): the host can then read it at any time
+    without a copy or a synchronisation once the call's completion event has fired.  ``FTN_RANGE_FLAG=device`` keeps it
+    in device memory (reading it then synchronises)."""
+    if os.getenv("FTN_RANGE_FLAG", "host") == "device":
+        return torch.zeros(1, dtype=torch.int32, device=device)
+    return torch.zeros(1, dtype=torch.int32).pin_memory()
+
+
 def fuse_stage_a(plan) -> bool:
     """Stage A can ride with the selector's finalize launch (bottleneck blocks; FTN_FUSE_STAGE_A=0 disables)."""
     return plan.mode == 0 and os.getenv("FTN_FUSE_STAGE_A", "1") != "0"
 
 
-def stage_a_only(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, k: int, pmax: int, min_thr: int):
+def stage_a_only(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, k: int, pmax: int, min_thr: int,
+                 range_flag: Optional[torch.Tensor] = None):
     """Stage A of the block into a fresh workspace, without the selection (``ftn_period_finalize_stage_a`` with
     ``psum = NULL``): a batch-sharded run launches it between issuing the exchange of the partial sums and waiting
     for it.  Returns the token ``finalize(..., stage_a=..., pre=token)`` completes."""
@@ -130,7 +145,8 @@ def stage_a_only(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, k: int, pm
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     check(lib.ftn_period_finalize_stage_a(None, 0, 0, None, B, L, int(k), int(pmax), int(min_thr), 0, 0, 0.0,
                                           None, None, None, _ptr(x), C.byref(plan), _ptr(wblob), mg, pxb, _ptr(ws),
-                                          ws.numel(), _stream(x.device)), "ftn_period_finalize_stage_a")
+                                          ws.numel(), _stream(x.device), _ptr_or_null(range_flag)),
+          "ftn_period_finalize_stage_a")
     return ws
 
 
@@ -155,7 +171,8 @@ def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int
     mg, pxb = _selector_bounds(lib, L, k, pmax, min_thr)
     sel = Selection(desc, amps, wts, mg, pxb)
     if stage_a is not None and (pre is not None or fuse_stage_a(stage_a[1])):
-        x, plan, wblob = stage_a
+        x, plan, wblob = stage_a[:3]
+        range_flag = stage_a[3] if len(stage_a) > 3 else None
         if pre is None:
             need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, sel.max_groups, sel.px_bound)
             if need == 0:
@@ -168,7 +185,7 @@ def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int
                                               float(log_base or 0.0), _ptr(desc), _ptr(amps), _ptr(wts),
                                               _ptr(x) if pre is None else None,
                                               C.byref(plan), _ptr(wblob), sel.max_groups, sel.px_bound, _ptr(ws),
-                                              ws.numel(), _stream(dev)),
+                                              ws.numel(), _stream(dev), _ptr_or_null(range_flag)),
               "ftn_period_finalize_stage_a")
         sel.stage_a = (ws, x.data_ptr(), C.addressof(plan))
         return sel
@@ -195,9 +212,9 @@ def selection_from_host(desc_host: FtnDesc, weights: torch.Tensor, device: torch
 
 # ------------------------------------------------------------------ conv path
 def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel: Selection,
-                       norm=None, act_dtype: int = 0) -> torch.Tensor:
+                       norm=None, act_dtype: int = 0, range_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``norm=(gamma, beta, eps)`` appends the model's per-block ``LayerNorm(x + (y - x))``
-    (reference :2050-2058) to the same call."""
+    (reference :2050-2058) to the same call.  ``range_flag``: see ``new_range_flag``."""
     lib = _lib.load()
     B, L, _ = x.shape
     need = lib.ftn_timesblock_workspace_bytes(C.byref(plan), B, L, sel.max_groups, sel.px_bound)
@@ -222,12 +239,12 @@ def timesblock_forward(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, sel:
         check(lib.ftn_timesblock_forward_norm(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
                                               _ptr(sel.weights), sel.max_groups, sel.px_bound, flags, _ptr(g), _ptr(b),
                                               float(eps),
-                                              _ptr(ws), ws.numel(), _stream(x.device)),
+                                              _ptr(ws), ws.numel(), _stream(x.device), _ptr_or_null(range_flag)),
               "ftn_timesblock_forward_norm")
         return y
     check(lib.ftn_timesblock_forward(_ptr(x), _ptr(y), B, L, C.byref(plan), _ptr(wblob), _ptr(sel.desc),
                                      _ptr(sel.weights), sel.max_groups, sel.px_bound, int(act_dtype), flags, _ptr(ws),
-                                     ws.numel(), _stream(x.device)), "ftn_timesblock_forward")
+                                     ws.numel(), _stream(x.device), _ptr_or_null(range_flag)), "ftn_timesblock_forward")
     return y
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTN_ABI_VERSION 8
+#define FTN_ABI_VERSION 9
 #define FTN_KMAX 16      /* max period candidates / groups per block call        */
 #define FTN_MAXBR 8      /* max kernels in kernel_set                             */
 
@@ -188,10 +188,15 @@ size_t ftn_timesblock_workspace_bytes(const FtnPlan* plan, int B, int L, int max
  * exactly where the reference rounds them (:1068-1069, :1092, :818), so y holds values of that dtype.
  * flags: FTN_FWD_STAGE_A_DONE = ftn_period_finalize_stage_a already ran stage A into this workspace. */
 #define FTN_FWD_STAGE_A_DONE 1
+/* range_flag (ABI 9; may be NULL): one int32 the kernels can write, in device memory or in pinned host memory the
+ * device can reach.  Engine f16x2 carries activations as fp16 pieces (|value| < 65504); the reference computes in
+ * fp32 (:1047-1056).  Wherever a value is split - x, the stage outputs a, m, a' - and at the final y (NaN / inf) the
+ * kernels test it and store 1 to *range_flag when it does not fit; the caller zeroes the word, and on 1 repeats the
+ * call with a plan of engine bf16x3 (full fp32 exponent range).  Other engines never touch it. */
 int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                            const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
                            int max_groups, int px_bound, int act_dtype, int flags, void* ws_dev, size_t ws_bytes,
-                           void* stream);
+                           void* stream, int* range_flag);
 /* ftn_period_finalize and stage A of the block (a = W_in1 x + b per window position, which does not depend on the
  * selector) in ONE launch: workgroup 0 is the finalize kernel and then publishes the sanitised descriptor copy at
  * the head of the workspace, the other workgroups compute stage A - the selector's single-workgroup tail (~17 us)
@@ -204,14 +209,15 @@ int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, int Btotal, 
                                 int k_periods, int pmax, int min_period_threshold, int act_dtype, int max_unique,
                                 float log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
                                 const float* x_dev, const FtnPlan* plan, const float* wblob_dev, int max_groups,
-                                int px_bound, void* ws_dev, size_t ws_bytes, void* stream);
+                                int px_bound, void* ws_dev, size_t ws_bytes, void* stream, int* range_flag);
 /* The same call followed by the caller's per-block epilogue of TimesNet.forward (:2050-2058, eval mode):
  *   y = LayerNorm_C( x + (block(x) - x) ; gamma, beta, eps )
  * fused into the last kernel when d_model <= 64 (bottleneck mode), one extra in-place row pass otherwise. */
 int ftn_timesblock_forward_norm(const float* x_dev, float* y_dev, int B, int L, const FtnPlan* plan,
                                 const float* wblob_dev, const FtnDesc* desc_dev, const float* weights_dev,
                                 int max_groups, int px_bound, int flags, const float* ln_gamma_dev,
-                                const float* ln_beta_dev, float ln_eps, void* ws_dev, size_t ws_bytes, void* stream);
+                                const float* ln_beta_dev, float ln_eps, void* ws_dev, size_t ws_bytes, void* stream,
+                                int* range_flag);
 /* out[row][:] = LayerNorm_C( x[row][:] + (new[row][:] - x[row][:]) ) for rows x C fp32 matrices (in place
  * allowed: out == new).  Used when a block returns x unchanged (no valid period, :796-797). */
 int ftn_residual_layernorm(const float* x_dev, const float* new_dev, float* out_dev, long long rows, int C,

@@ -266,7 +266,7 @@ def test_descriptor_beyond_declared_bounds_is_identity(ftn, dev):
         y = torch.full_like(x, float("nan"))
         ftn.lib.check(lib.ftn_timesblock_forward(x.data_ptr(), y.data_ptr(), B, L, ctypes.byref(plan),
                                                  wblob.data_ptr(), sel.desc.data_ptr(), sel.weights.data_ptr(), mg, pxb, 0, 0,
-                                                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                                                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream, None),
                       "ftn_timesblock_forward")
         torch.cuda.synchronize()
         assert torch.equal(y, x)

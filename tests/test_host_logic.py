@@ -213,25 +213,25 @@ def test_c_abi_rejects_bad_arguments_before_any_launch(ftn):
     fake = 1 << 20                                        # a non-null, 256-aligned "device pointer": never dereferenced
     # fused finalize + stage A: nothing to do (psum and x both NULL)
     rc = lib.ftn_period_finalize_stage_a(None, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake, fake, None,
-                                         C.byref(plan), fake, mg.value, pxb, fake, need, None)
+                                         C.byref(plan), fake, mg.value, pxb, fake, need, None, None)
     assert rc < 0 and b"nothing to do" in lib.ftn_last_error()
     # workspace too small
     rc = lib.ftn_period_finalize_stage_a(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake, fake, fake,
-                                         C.byref(plan), fake, mg.value, pxb, fake, need - 1, None)
+                                         C.byref(plan), fake, mg.value, pxb, fake, need - 1, None, None)
     assert rc < 0 and b"workspace" in lib.ftn_last_error()
     # misaligned amps / weights
     rc = lib.ftn_period_finalize(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake + 4, fake, None)
     assert rc < 0 and b"aligned" in lib.ftn_last_error()
     # unknown flag bit / stage-A flag on a plan that is not a bottleneck block
-    rc = lib.ftn_timesblock_forward(fake, fake, B, L, C.byref(plan), fake, fake, fake, mg.value, pxb, 0, 2, fake, need, None)
+    rc = lib.ftn_timesblock_forward(fake, fake, B, L, C.byref(plan), fake, fake, fake, mg.value, pxb, 0, 2, fake, need, None, None)
     assert rc < 0 and b"flags" in lib.ftn_last_error()
     sd1 = ftn.synth.make_inception_params(16, 16, [(3, 3)], 1.0, 0)
     _, plan1 = ftn.pack.pack_inception(sd1, 16, 16, [(3, 3)], 1.0, "gelu", "f32")
     need1 = lib.ftn_timesblock_workspace_bytes(C.byref(plan1), B, L, mg.value, pxb)
-    rc = lib.ftn_timesblock_forward(fake, fake, B, L, C.byref(plan1), fake, fake, fake, mg.value, pxb, 0, 1, fake, need1, None)
+    rc = lib.ftn_timesblock_forward(fake, fake, B, L, C.byref(plan1), fake, fake, fake, mg.value, pxb, 0, 1, fake, need1, None, None)
     assert rc < 0 and b"flags" in lib.ftn_last_error()
     rc = lib.ftn_period_finalize_stage_a(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake, fake, fake,
-                                         C.byref(plan1), fake, mg.value, pxb, fake, max(need, need1), None)
+                                         C.byref(plan1), fake, mg.value, pxb, fake, max(need, need1), None, None)
     assert rc < 0 and b"bottleneck" in lib.ftn_last_error()
 
 
