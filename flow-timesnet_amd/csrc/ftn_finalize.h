@@ -27,7 +27,7 @@ struct FinalizeArgs {
   const double* psum; int nparts, Btotal;
   const float* med; int B, L, F, kcfg, pmax, min_thr;
   FtnDesc* desc; float* amps; float* wts;
-  int act_dtype, max_unique; float log_base;
+  int act_dtype, max_unique; float log_den;   // log_den = (float)log(base) of TIMES_PERIOD_BINNING, evaluated in double on the host (0 = off)
 };
 
 // One 256-thread workgroup.  Dynamic LDS: F floats.
@@ -40,7 +40,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
   float* __restrict__ amps = fa.amps;
   float* __restrict__ wts = fa.wts;
   const int act_dtype = fa.act_dtype, max_unique = fa.max_unique;
-  const float log_base = fa.log_base;
+  const float log_den = fa.log_den;
   extern __shared__ __attribute__((aligned(16))) float score[];  // [F]
   __shared__ int sel_idx[FTN_KMAX];
   __shared__ FtnDesc sd;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
   //      groups with the largest batch-mean logsumexp survive, the others joining the kept group of nearest
   //      period.  A group's period is its member with the largest batch-mean amplitude.  Needs two reductions
   //      over the batch (column means, group scores), done in a fixed order; the small-K logic runs on thread 0.
-  if (max_unique > 0 || log_base > 1.0f) {
+  if (max_unique > 0 || log_den > 0.0f) {
     const int nsel = sd.n_sel;
     float part[FTN_KMAX];
 #pragma unroll
@@ -206,7 +206,8 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
         const int p = sd.sel_period[j];
         bool ok = p > 0 && p >= min_thr && p <= pmax;
         if (ok) { const int pad = (p - (L % p)) % p; ok = (L + pad) / p >= 2; }
-        key[j] = !ok ? -1 : (log_base > 1.0f ? (int)floorf(logf((float)p) / logf(log_base) + 1e-6f) : p);   // :350-354
+        // :350-354: torch divides the fp32 log of the period by math.log(base) (a double, rounded to fp32 as the scalar operand)
+        key[j] = !ok ? -1 : (log_den > 0.0f ? (int)floorf(logf((float)p) / log_den + 1e-6f) : p);
         if (!ok) continue;
         // assignment id = rank of the key among the distinct keys (sorted ascending), filled below
       }

@@ -2986,7 +2986,7 @@ static int finalize_stage_a_t(const FinalizeArgs& fa, const PwArgs& pa, int epi,
 
 extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B,
                                            int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
-                                           int max_unique, float log_base, FtnDesc* desc_dev, float* amps_dev,
+                                           int max_unique, double log_base, FtnDesc* desc_dev, float* amps_dev,
                                            float* weights_dev, const float* x_dev, const FtnPlan* plan,
                                            const float* wblob_dev, int max_groups, int px_bound, void* ws_dev,
                                            size_t ws_bytes, void* stream, int* range_flag_dev) {
@@ -3021,7 +3021,7 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
   const bool use_bf = plan->engine != 0 && bfg.NCO > 0;
   const int epi = !use_bf ? 0 : (plan->engine == 3 ? 3 : 2);
   FinalizeArgs fa = {psum_dev, nparts, Btotal, med_dev, B, L, F, k_periods, pmax, min_period_threshold, desc_dev,
-                     amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0f ? log_base : 0.f};
+                     amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0 ? (float)log(log_base) : 0.f};
   PwArgs pa = {};
   pa.x = x_dev; pa.W = wblob_dev + plan->w_in1; pa.bias = wblob_dev + plan->b_in1; pa.out = (float*)((char*)ws_dev + wl.offA);
   pa.desc = nullptr; pa.B = B; pa.L = L; pa.C = plan->C; pa.KIN = plan->CP; pa.n_ot = CA / 16; pa.OUTC = CA;

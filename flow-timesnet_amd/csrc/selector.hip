@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs fa) { finalize_bo
 
 extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B,
                                    int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
-                                   int max_unique, float log_base, FtnDesc* desc_dev, float* amps_dev,
+                                   int max_unique, double log_base, FtnDesc* desc_dev, float* amps_dev,
                                    float* weights_dev, void* stream) {
   FTN_CHECK_ARG(psum_dev && med_dev && desc_dev && amps_dev && weights_dev, "ftn_period_finalize: null pointer");
   FTN_CHECK_ARG((((uintptr_t)amps_dev | (uintptr_t)weights_dev) & 15) == 0, "ftn_period_finalize: amps / weights must be 16-byte aligned");
@@ -747,7 +747,7 @@ extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btota
   const size_t lds = (size_t)F * sizeof(float);
   FTN_CHECK_ARG(lds <= 48 * 1024, "ftn_period_finalize: L=%d too long", L);
   FinalizeArgs fa = {psum_dev, nparts, Btotal, med_dev, B, L, F, k_periods, pmax, min_period_threshold, desc_dev,
-                     amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0f ? log_base : 0.f};
+                     amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0 ? (float)log(log_base) : 0.f};
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), lds, (hipStream_t)stream, fa);
   FTN_CHECK_LAUNCH();
   return 0;

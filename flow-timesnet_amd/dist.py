@@ -24,6 +24,18 @@ import torch.distributed as dist
 from torch import nn
 
 
+def _refuse_flagged_grouping(block_index=None) -> None:
+    """The reference's TIMES_PERIOD_MAX_UNIQ / TIMES_PERIOD_BINNING grouping variants rank candidate groups by batch
+    means of the amplitudes (:374-378, :394-437).  A sharded run exchanges only the [F] spectrum sums, so each rank
+    would rank on its own rows and the ranks could keep different groups: refuse instead of diverging silently."""
+    from .grouping import _resolve_log_binning_base, _resolve_scheduled_int
+
+    if (_resolve_scheduled_int(os.getenv("TIMES_PERIOD_MAX_UNIQ"), block_index) or
+            _resolve_log_binning_base(os.getenv("TIMES_PERIOD_BINNING"), block_index)):
+        raise NotImplementedError("TIMES_PERIOD_MAX_UNIQ / TIMES_PERIOD_BINNING are not supported with a batch-sharded "
+                                  "selector: unset them or run unsharded")
+
+
 def gather_batch(y_local: torch.Tensor, group=None, async_op: bool = False):
     """All-gather equal-sized shards along dim 0 -> ``[world*B_local, ...]`` on every rank.
 
@@ -64,6 +76,8 @@ class ShardedTimesBlock(nn.Module):
         which lets a serving loop overlap step i's output exchange with step i+1's compute."""
         sel = self.block.period_selector
         grp = self.group if self.group is not None else dist.group.WORLD
+        if dist.get_world_size(grp) > 1:
+            _refuse_flagged_grouping(getattr(self.block, "block_index", None))
         prev = sel.shard_group
         sel.shard_group = grp if (dist.get_world_size(grp) > 1 or os.environ.get("FTN_BENCH_FORCE_DIST") == "1") else None
         try:
@@ -91,6 +105,9 @@ class ShardedTimesNet(nn.Module):
     def forward(self, x_local: torch.Tensor, gather: bool = False, **kwargs):
         sel = self.model.period_selector
         grp = self.group if self.group is not None else dist.group.WORLD
+        if dist.get_world_size(grp) > 1:
+            for blk in self.model.blocks:
+                _refuse_flagged_grouping(getattr(blk, "block_index", None))
         prev = sel.shard_group
         sel.shard_group = grp if (dist.get_world_size(grp) > 1 or os.environ.get("FTN_BENCH_FORCE_DIST") == "1") else None
         try:

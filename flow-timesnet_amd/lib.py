@@ -92,7 +92,7 @@ _SIGNATURES = {
     "ftn_dft_table_init": (C.c_int, [_P, C.c_int, _P]),
     "ftn_period_spectrum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "ftn_period_finalize": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, C.c_float, _P, _P, _P, _P]),
+                                      C.c_int, C.c_double, _P, _P, _P, _P]),
     "ftn_desc_from_periods": (C.c_int, [C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(FtnDesc)]),
     "ftn_selector_px_bound": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
@@ -102,7 +102,7 @@ _SIGNATURES = {
     "ftn_timesblock_forward_norm": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FtnPlan), _P, _P, _P, C.c_int,
                                               C.c_int, C.c_int, _P, _P, C.c_float, _P, C.c_size_t, _P, _P]),
     "ftn_period_finalize_stage_a": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                              C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, C.POINTER(FtnPlan), _P,
+                                              C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, C.POINTER(FtnPlan), _P,
                                               C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
     "ftn_residual_layernorm": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int, _P, _P, C.c_float, _P]),
     "ftn_head_forward": (C.c_int, [_P, C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_longlong,
@@ -139,21 +139,45 @@ def load() -> C.CDLL:
         import subprocess
 
         hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if Path("/opt/rocm/bin/hipcc").exists() else None)
-        if shutil.which("make") and hipcc:
+        csrc = _HERE / "csrc"
+
+        def current() -> bool:
+            """The library exists and is newer than every source it is built from."""
+            if not path.exists():
+                return False
+            srcs = [*csrc.glob("*.hip"), *csrc.glob("*.h"), csrc / "Makefile", _HERE.parent / "include" / "flowtimes.h"]
+            return all(not f.exists() or f.stat().st_mtime <= path.stat().st_mtime for f in srcs)
+
+        if shutil.which("make") and hipcc and not (current() and not os.access(csrc, os.W_OK)):
             import fcntl
 
             # one builder at a time: the ranks of a multi-GPU launch all arrive here together
-            with open(_HERE / "csrc" / ".build.lock", "w") as lock:
-                fcntl.flock(lock, fcntl.LOCK_EX)
-                try:
-                    proc = subprocess.run(["make", "-C", str(_HERE / "csrc"), "-j4"], check=False,
-                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-                    if proc.returncode != 0:
-                        build_log = proc.stdout[-4000:]
-                finally:
-                    fcntl.flock(lock, fcntl.LOCK_UN)
+            try:
+                lock = open(csrc / ".build.lock", "w")
+            except OSError as exc:                              # read-only tree (an installed copy)
+                if not current():
+                    raise FlowTimesLibraryError(f"{csrc} is not writable and {path} is missing or older than its "
+                                                f"sources: {exc}") from exc
+                lock = None
+            if lock is not None:
+                with lock:
+                    fcntl.flock(lock, fcntl.LOCK_EX)
+                    try:
+                        proc = subprocess.run(["make", "-C", str(csrc), "-j4"], check=False,
+                                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                        if proc.returncode != 0:
+                            build_log = proc.stdout[-4000:]
+                    finally:
+                        fcntl.flock(lock, fcntl.LOCK_UN)
             if build_log:
-                raise FlowTimesLibraryError(f"building {path} failed; there is no fallback path:\n{build_log}")
+                # a broken toolchain beside a library that is provably current (newer than every source) is not a
+                # stale-library risk: use it and say so; anything else stays an error
+                if not current():
+                    raise FlowTimesLibraryError(f"building {path} failed; there is no fallback path:\n{build_log}")
+                import warnings
+
+                warnings.warn(f"`make` failed but {path.name} is newer than all of its sources - using it.\n{build_log[-500:]}",
+                              RuntimeWarning, stacklevel=2)
     if not path.exists():
         raise FlowTimesLibraryError(
             f"{path} not found: build it with `make -C {_HERE / 'csrc'}` "

@@ -139,6 +139,11 @@ class FFTPeriodSelector(nn.Module):
         if self.shard_group is not None:
             import torch.distributed as dist
 
+            if (max_unique or 0) > 0 or (log_base or 0.0) > 1.0:
+                # those variants rank candidate groups by batch means of the amplitudes (:374-378, :394-437); only the
+                # [F] sums are exchanged, so every rank would rank on its own rows and could keep different groups
+                raise NotImplementedError("TIMES_PERIOD_MAX_UNIQ / TIMES_PERIOD_BINNING are not supported with a "
+                                          "batch-sharded selector (shard_group): unset them or run unsharded")
             world = dist.get_world_size(self.shard_group)
             parts = torch.empty(world, psum.numel(), dtype=psum.dtype, device=psum.device)
             # the block's stage A needs x only: it runs while the partial sums travel

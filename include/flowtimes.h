@@ -155,11 +155,12 @@ int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* tab
  * weights (:1000) and their scatter-added group sums (:1009) to that dtype; the kernel applies the same
  * roundings (the values are still delivered as fp32).
  * max_unique / log_base: the reference's TIMES_PERIOD_MAX_UNIQ / TIMES_PERIOD_BINNING grouping variants
- * (:350-437) with the per-depth schedule already resolved by the caller; 0 / 0.f = unset (plain
- * duplicate-merge grouping). */
+ * (:350-437) with the per-depth schedule already resolved by the caller; 0 / 0.0 = unset (plain
+ * duplicate-merge grouping).  log_base is a double (ABI 9): the bucket is floor(log(p) / log(base) + 1e-6) with the
+ * fp32 log of the period divided by (float)log(base), base in double - torch's operand order (:352). */
 int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev,
                         int B, int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
-                        int max_unique, float log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
+                        int max_unique, double log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
                         void* stream);
 /* Host-only: PeriodGrouper.group (:513-557, env flags unset) + conv tiling for
  * periods that come from somewhere else (stub selectors in the reference tests).
@@ -207,7 +208,7 @@ int ftn_timesblock_forward(const float* x_dev, float* y_dev, int B, int L, const
  * amps / weights unused),  x_dev == NULL runs S3-S5 and the descriptor copy only. */
 int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B, int L,
                                 int k_periods, int pmax, int min_period_threshold, int act_dtype, int max_unique,
-                                float log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
+                                double log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
                                 const float* x_dev, const FtnPlan* plan, const float* wblob_dev, int max_groups,
                                 int px_bound, void* ws_dev, size_t ws_bytes, void* stream, int* range_flag);
 /* The same call followed by the caller's per-block epilogue of TimesNet.forward (:2050-2058, eval mode):

@@ -54,6 +54,13 @@ def _worker(rank, world, port, name, out_dir):
             work.wait()
             assert torch.equal(y_async, y)
         assert blk.period_selector.shard_group is None          # restored after the call
+        # the flagged grouping variants would rank groups on each rank's own rows: refused, not diverging
+        os.environ["TIMES_PERIOD_MAX_UNIQ"] = "2"
+        try:
+            with pytest.raises(NotImplementedError):
+                runner(shard, gather=False)
+        finally:
+            del os.environ["TIMES_PERIOD_MAX_UNIQ"]
         np.save(os.path.join(out_dir, f"y{rank}.npy"), y.numpy())
         np.save(os.path.join(out_dir, f"p{rank}.npy"), blk.period_selector.last_selected_periods.numpy())
         assert torch.equal(y.chunk(world, dim=0)[rank], y_local)
