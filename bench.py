@@ -188,7 +188,10 @@ def run_rank(args) -> None:
 
     if use_dist:
         import torch.distributed as dist
-        runner = pkg.dist.ShardedTimesBlock(blk)
+        # FTN_EXCHANGE=ipc: the partial sums travel as peer stores into IPC-mapped buffers (dist.IpcExchange) instead
+        # of an all-gather launch
+        exchange = pkg.dist.IpcExchange(None, dev) if os.environ.get("FTN_EXCHANGE") == "ipc" else None
+        runner = pkg.dist.ShardedTimesBlock(blk, exchange=exchange)
         pending = []
 
         def step(xx=None):
@@ -215,6 +218,7 @@ def run_rank(args) -> None:
     else:
         step = lambda xx=None: blk(x if xx is None else xx)
         step_gather = None
+        exchange = None
         drain = lambda: None
         barrier = lambda: None
 
@@ -504,6 +508,7 @@ def run_rank(args) -> None:
                        "windows_per_s": B_global / (elapsed / args.steps), "periods": periods, "groups": G,
                        "parallelism": (f"batch-shard x{dist_world} (torch.distributed world size, backend "
                                        f"{os.environ.get('FTN_BENCH_BACKEND', 'nccl')}"
+                                       f"{', partial sums by IPC peer stores' if os.environ.get('FTN_EXCHANGE') == 'ipc' else ''}"
                                        f"{', REHEARSAL: ranks share GPUs' if os.environ.get('FTN_BENCH_SHARE_GPU') == '1' else ''}): one "
                                        "all-gather of [F] fp64 partial sums per step, outputs stay sharded"
                                        if use_dist else "single")},
@@ -554,6 +559,9 @@ def run_rank(args) -> None:
         print(json.dumps(out), flush=True)
     if use_dist:
         import torch.distributed as dist
+        if exchange is not None:
+            exchange.check()
+            exchange.close()
         dist.barrier()
         dist.destroy_process_group()
 

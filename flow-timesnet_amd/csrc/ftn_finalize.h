@@ -28,7 +28,18 @@ struct FinalizeArgs {
   const float* med; int B, L, F, kcfg, pmax, min_thr;
   FtnDesc* desc; float* amps; float* wts;
   int act_dtype, max_unique; float log_den;   // log_den = (float)log(base) of TIMES_PERIOD_BINNING, evaluated in double on the host (0 = off)
+  // multi-GPU exchange (FtnExchange): the nparts partial sums are peer-written slots; ready[p * ready_n + i] turns
+  // ready_seq when block i of rank p's k_colsum has stored its columns.  psum rows are psum_stride doubles apart.
+  const unsigned long long* ready; unsigned long long ready_seq; int ready_n, psum_stride; int* xerr;
 };
+
+// exchange buffer of one rank: two halves (seq parity); per half [world][F_cap] doubles, then [world][FTN_XCHG_NBLK]
+// sequence words; one error word at the very end
+#define FTN_XCHG_NBLK 32
+__host__ __device__ inline size_t ftn_xchg_half_bytes(int world, int F_cap) {
+  return ((size_t)world * ((size_t)F_cap * 8 + FTN_XCHG_NBLK * 8) + 255) & ~(size_t)255;
+}
+__host__ __device__ inline size_t ftn_xchg_flags_off(int world, int F_cap) { return (size_t)world * F_cap * 8; }
 
 // One 256-thread workgroup.  Dynamic LDS: F floats.
 __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
@@ -50,10 +61,37 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
   __shared__ int c_assign[FTN_KMAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+  const int pstride = fa.psum_stride > 0 ? fa.psum_stride : F;
+  __shared__ int peers_late;
+  if (fa.ready != nullptr) {
+    // every (rank, column block) sequence word must have turned ready_seq.  Bounded wait: s_memrealtime ticks at
+    // 100 MHz, 2 s = 2e8 ticks - a peer that died must not hang this GPU.  System-scope loads: the words and the
+    // slots are written by other GPUs (or, in a rehearsal, other processes) and must not come from a stale cache line.
+    if (tid == 0) peers_late = 0;
+    __syncthreads();
+    const int nflag = nparts * fa.ready_n;
+    for (int i = tid; i < nflag; i += 256) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(fa.ready + (size_t)(i / fa.ready_n) * FTN_XCHG_NBLK + (i % fa.ready_n), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM) != fa.ready_seq) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { peers_late = 1; break; }
+        __builtin_amdgcn_s_sleep(32);
+      }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (peers_late && tid == 0 && fa.xerr != nullptr) __hip_atomic_store(fa.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   // mean over the (global) batch, DC kill, log penalty          (:112-130)
   for (int f = tid; f < F; f += 256) {
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += psum[(size_t)p * F + f];
+    for (int p = 0; p < nparts; ++p) {
+      const double* src = psum + (size_t)p * pstride + f;
+      s += fa.ready != nullptr ? __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)src, __ATOMIC_RELAXED,
+                                                                              __HIP_MEMORY_SCOPE_SYSTEM))
+                               : *src;
+    }
+    if (fa.ready != nullptr && peers_late) s = 0.0 / 0.0;       // no valid period below: the block becomes the identity
     float m = rnd_act((float)(s / (double)Btotal), act_dtype);
     float sc = rnd_act(m - rnd_act(1e-8f * rnd_act(log1pf((float)f), act_dtype), act_dtype), act_dtype);
     score[f] = (f == 0) ? -INFINITY : sc;

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void k_pw(PwArgs a) { pw_body<ACT, XIN, XVEC, 
 // sanitised descriptor copy at the head of the workspace), workgroups 1.. are stage A - so stage A's ~22 us
 // disappear behind the selector's tail (ftn_period_finalize_stage_a).
 #include "ftn_finalize.h"
+void ftn_xch_fill(const FtnExchange* x, int F, FinalizeArgs* fa);   // selector.hip
 // part: 0 = both (workgroup 0 finalizes, the others run stage A), 1 = stage A only (a sharded batch runs it while
 // the partial sums are exchanged), 2 = finalize + descriptor copy only (one workgroup, after that exchange)
 template <int ACT, bool XVEC, int EPI>
@@ -2989,9 +2990,15 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
                                            int max_unique, double log_base, FtnDesc* desc_dev, float* amps_dev,
                                            float* weights_dev, const float* x_dev, const FtnPlan* plan,
                                            const float* wblob_dev, int max_groups, int px_bound, void* ws_dev,
-                                           size_t ws_bytes, void* stream, int* range_flag_dev) {
+                                           size_t ws_bytes, void* stream, int* range_flag_dev, const FtnExchange* xch) {
   // psum_dev == NULL: stage A only;  x_dev == NULL: finalize + descriptor copy only (stage A is in the workspace)
-  const bool do_fin = psum_dev != nullptr, do_a = x_dev != nullptr;
+  const bool do_fin = psum_dev != nullptr || xch != nullptr, do_a = x_dev != nullptr;
+  if (xch != nullptr) {
+    FTN_CHECK_ARG(xch->world >= 1 && xch->world <= FTN_XCHG_MAXWORLD && xch->rank >= 0 && xch->rank < xch->world &&
+                  xch->seq > 0 && L / 2 + 1 <= xch->F_cap && xch->slots[xch->rank] != nullptr,
+                  "ftn_period_finalize_stage_a: bad exchange (world / rank / seq / F_cap)");
+    nparts = xch->world;
+  }
   FTN_CHECK_ARG(do_fin || do_a, "ftn_period_finalize_stage_a: nothing to do (psum and x both null)");
   FTN_CHECK_ARG(plan && wblob_dev && ws_dev, "ftn_period_finalize_stage_a: null pointer");
   if (do_fin) {
@@ -3022,6 +3029,7 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
   const int epi = !use_bf ? 0 : (plan->engine == 3 ? 3 : 2);
   FinalizeArgs fa = {psum_dev, nparts, Btotal, med_dev, B, L, F, k_periods, pmax, min_period_threshold, desc_dev,
                      amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0 ? (float)log(log_base) : 0.f};
+  if (xch != nullptr) ftn_xch_fill(xch, F, &fa);
   PwArgs pa = {};
   pa.x = x_dev; pa.W = wblob_dev + plan->w_in1; pa.bias = wblob_dev + plan->b_in1; pa.out = (float*)((char*)ws_dev + wl.offA);
   pa.desc = nullptr; pa.B = B; pa.L = L; pa.C = plan->C; pa.KIN = plan->CP; pa.n_ot = CA / 16; pa.OUTC = CA;

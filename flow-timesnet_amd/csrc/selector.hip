@@ -9,7 +9,9 @@
 //                       periods, grouping, tiling, softmax weights -> FtnDesc, amps, w
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include "ftn_common.h"
+#include "ftn_finalize.h"
 
 // ---------------------------------------------------------------- twiddle table
 // cos table [L][FPAD] followed by sin table [L][FPAD]; FPAD = F rounded up to 32,
@@ -660,8 +662,17 @@ __global__ __launch_bounds__(1024) void k_spectrum_rowq(const float* __restrict_
 
 // psum[f] = sum_b med[b][f] in fp64, fixed order: 32 row-strided partial sums per column, combined in index
 // order (bitwise reproducible; no atomics).
+// With an exchange (XchArgs.world > 0) block i also stores its 32 columns into slot `rank` of every rank's exchange
+// buffer (peer device memory, mapped through hipIpcOpenMemHandle) and then turns that slot's sequence word i: plain
+// stores, a system-scope fence, a system-scope store of the word - the consumer is ftn_finalize.h's bounded wait.
+struct XchArgs {
+  char* half[FTN_XCHG_MAXWORLD];     // this call's half of every rank's buffer
+  int world, rank, F_cap;
+  unsigned long long seq;
+};
+
 __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ med, int B, int F,
-                                                 double* __restrict__ psum) {
+                                                 double* __restrict__ psum, XchArgs xa) {
   __shared__ double part[32][33];
   const int fl = threadIdx.x & 31, bl = threadIdx.x >> 5;
   const int f = blockIdx.x * 32 + fl;
@@ -675,12 +686,103 @@ __global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ med, 
 #pragma unroll
     for (int k = 0; k < 32; ++k) t += part[k][fl];
     psum[f] = t;
+    for (int r = 0; r < xa.world; ++r) ((double*)xa.half[r])[(size_t)xa.rank * xa.F_cap + f] = t;
+  }
+  if (xa.world > 0 && bl == 0) {                                // wave 0 of the block holds all 32 storing lanes
+    __threadfence_system();
+    if (fl == 0)
+      for (int r = 0; r < xa.world; ++r)
+        __hip_atomic_store((unsigned long long*)(xa.half[r] + ftn_xchg_flags_off(xa.world, xa.F_cap)) +
+                               (size_t)xa.rank * FTN_XCHG_NBLK + blockIdx.x,
+                           xa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
+extern "C" size_t ftn_exchange_bytes(int world, int F_cap) {
+  if (world < 1 || world > FTN_XCHG_MAXWORLD || F_cap < 2 || F_cap > 32 * FTN_XCHG_NBLK) return 0;
+  return 2 * ftn_xchg_half_bytes(world, F_cap) + 256;           // two halves + the error word's line
+}
+
+static bool xch_ok(const FtnExchange* x, int F) {
+  return x->world >= 1 && x->world <= FTN_XCHG_MAXWORLD && x->rank >= 0 && x->rank < x->world && x->seq > 0 &&
+         F <= x->F_cap && x->F_cap <= 32 * FTN_XCHG_NBLK && x->slots[x->rank] != nullptr;
+}
+static bool xch_mapped(const FtnExchange* x) {
+  for (int r = 0; r < x->world; ++r)
+    if (x->slots[r] == nullptr) return false;
+  return true;
+}
+static char* xch_half(const FtnExchange* x, int r) {
+  return (char*)x->slots[r] + (size_t)(x->seq & 1) * ftn_xchg_half_bytes(x->world, x->F_cap);
+}
+int* ftn_xch_err_word(const FtnExchange* x) {
+  return (int*)((char*)x->slots[x->rank] + 2 * ftn_xchg_half_bytes(x->world, x->F_cap));
+}
+// the finalize side of an exchange: psum rows = the world slots of this rank's own buffer
+void ftn_xch_fill(const FtnExchange* x, int F, FinalizeArgs* fa) {
+  char* mine = xch_half(x, x->rank);
+  fa->psum = (const double*)mine;
+  fa->nparts = x->world;
+  fa->psum_stride = x->F_cap;
+  fa->ready = (const unsigned long long*)(mine + ftn_xchg_flags_off(x->world, x->F_cap));
+  fa->ready_seq = x->seq;
+  fa->ready_n = (F + 31) / 32;
+  fa->xerr = ftn_xch_err_word(x);
+}
+
+// One rank's exchange buffer: allocated and zeroed here (hipMalloc: its own allocation, which is what an IPC handle
+// names), exported as a 64-byte handle the other ranks open.
+extern "C" int ftn_exchange_alloc(int world, int F_cap, void** buf_out, void* handle64_out) {
+  const size_t n = ftn_exchange_bytes(world, F_cap);
+  FTN_CHECK_ARG(n > 0 && buf_out && handle64_out, "ftn_exchange_alloc: world=%d F_cap=%d", world, F_cap);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, n);
+  if (e == hipSuccess) e = hipMemset(p, 0, n);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64_out, p);
+  if (e != hipSuccess) {
+    ftn_set_error("ftn_exchange_alloc: %s", hipGetErrorString(e));
+    if (p) (void)hipFree(p);
+    return (int)e;
+  }
+  *buf_out = p;
+  return 0;
+}
+extern "C" int ftn_exchange_open(const void* handle64, void** mapped_out) {
+  FTN_CHECK_ARG(handle64 && mapped_out, "ftn_exchange_open: null pointer");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  hipError_t e = hipIpcOpenMemHandle(mapped_out, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) { ftn_set_error("hipIpcOpenMemHandle: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+extern "C" int ftn_exchange_close(void* mapped) {
+  hipError_t e = mapped ? hipIpcCloseMemHandle(mapped) : hipSuccess;
+  if (e != hipSuccess) { ftn_set_error("hipIpcCloseMemHandle: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+extern "C" int ftn_exchange_free(void* buf) {
+  hipError_t e = buf ? hipFree(buf) : hipSuccess;
+  if (e != hipSuccess) { ftn_set_error("hipFree: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+extern "C" int ftn_exchange_error(const FtnExchange* xch, void* stream) {
+  FTN_CHECK_ARG(xch && xch->world >= 1 && xch->world <= FTN_XCHG_MAXWORLD && xch->rank >= 0 && xch->rank < xch->world &&
+                xch->slots[xch->rank], "ftn_exchange_error: bad exchange");
+  int v = 0;
+  hipError_t e = hipMemcpyAsync(&v, ftn_xch_err_word(xch), sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) { ftn_set_error("ftn_exchange_error: %s", hipGetErrorString(e)); return -(int)e - 1000; }
+  return v;
+}
+
 extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* table_dev,
-                                   float* med_dev, double* psum_dev, void* stream) {
+                                   float* med_dev, double* psum_dev, void* stream, const FtnExchange* xch) {
   FTN_CHECK_ARG(x_dev && table_dev && med_dev && psum_dev, "ftn_period_spectrum: null pointer");
+  FTN_CHECK_ARG(xch == nullptr || xch_ok(xch, L / 2 + 1), "ftn_period_spectrum: bad exchange (world / rank / seq / F_cap)");
+  FTN_CHECK_ARG(xch == nullptr || xch_mapped(xch), "ftn_period_spectrum: an exchange slot is not mapped");
   FTN_CHECK_ARG(B >= 1 && L >= 2 && C >= 1, "ftn_period_spectrum: bad shape B=%d L=%d C=%d", B, L, C);
   FTN_CHECK_ARG((long long)(B + 7) * (fpad_of(L) / 32) < 0x7fffffffLL, "ftn_period_spectrum: B=%d too large", B);
   const int F = L / 2 + 1, FPAD = fpad_of(L);
@@ -719,21 +821,26 @@ extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, cons
                        B, L, C, (const float*)table_dev, F, FPAD, med_dev, getenv("FTN_SEL_FLAT") != nullptr ? 1 : 0);
   }
   FTN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_colsum, dim3(ftn_cdiv(F, 32)), dim3(1024), 0, (hipStream_t)stream, med_dev, B, F, psum_dev);
+  XchArgs xa = {};
+  if (xch != nullptr) {
+    for (int r = 0; r < xch->world; ++r) xa.half[r] = xch_half(xch, r);
+    xa.world = xch->world; xa.rank = xch->rank; xa.F_cap = xch->F_cap; xa.seq = xch->seq;
+  }
+  hipLaunchKernelGGL(k_colsum, dim3(ftn_cdiv(F, 32)), dim3(1024), 0, (hipStream_t)stream, med_dev, B, F, psum_dev, xa);
   FTN_CHECK_LAUNCH();
   return 0;
 }
 
 // ---------------------------------------------------------------- S3 - S5
-#include "ftn_finalize.h"
-
 __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs fa) { finalize_body(fa); }
 
 extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev, int B,
                                    int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
                                    int max_unique, double log_base, FtnDesc* desc_dev, float* amps_dev,
-                                   float* weights_dev, void* stream) {
-  FTN_CHECK_ARG(psum_dev && med_dev && desc_dev && amps_dev && weights_dev, "ftn_period_finalize: null pointer");
+                                   float* weights_dev, void* stream, const FtnExchange* xch) {
+  FTN_CHECK_ARG((psum_dev || xch) && med_dev && desc_dev && amps_dev && weights_dev, "ftn_period_finalize: null pointer");
+  FTN_CHECK_ARG(xch == nullptr || xch_ok(xch, L / 2 + 1), "ftn_period_finalize: bad exchange (world / rank / seq / F_cap)");
+  if (xch != nullptr) nparts = xch->world;
   FTN_CHECK_ARG((((uintptr_t)amps_dev | (uintptr_t)weights_dev) & 15) == 0, "ftn_period_finalize: amps / weights must be 16-byte aligned");
   FTN_CHECK_ARG(B >= 1 && L >= 2 && nparts >= 1 && Btotal >= B, "ftn_period_finalize: bad shape");
   FTN_CHECK_ARG(k_periods <= FTN_KMAX, "ftn_period_finalize: k_periods=%d > FTN_KMAX=%d", k_periods, FTN_KMAX);
@@ -748,6 +855,7 @@ extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btota
   FTN_CHECK_ARG(lds <= 48 * 1024, "ftn_period_finalize: L=%d too long", L);
   FinalizeArgs fa = {psum_dev, nparts, Btotal, med_dev, B, L, F, k_periods, pmax, min_period_threshold, desc_dev,
                      amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0 ? (float)log(log_base) : 0.f};
+  if (xch != nullptr) ftn_xch_fill(xch, F, &fa);
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), lds, (hipStream_t)stream, fa);
   FTN_CHECK_LAUNCH();
   return 0;

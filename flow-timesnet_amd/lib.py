@@ -23,6 +23,16 @@ class FlowTimesLibraryError(RuntimeError):
     pass
 
 
+FTN_XCHG_MAXWORLD = 16
+
+
+class FtnExchange(C.Structure):
+    """Mirror of ``struct FtnExchange`` (include/flowtimes.h): the peer-mapped exchange buffers of a batch-sharded run."""
+
+    _fields_ = [("slots", C.c_void_p * FTN_XCHG_MAXWORLD), ("world", C.c_int32), ("rank", C.c_int32),
+                ("F_cap", C.c_int32), ("seq", C.c_uint64)]
+
+
 class FtnDesc(C.Structure):
     """Mirror of ``struct FtnDesc`` (include/flowtimes.h)."""
 
@@ -90,9 +100,15 @@ _SIGNATURES = {
                                              C.c_double, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(FtnPlan)]),
     "ftn_dft_table_bytes": (C.c_size_t, [C.c_int]),
     "ftn_dft_table_init": (C.c_int, [_P, C.c_int, _P]),
-    "ftn_period_spectrum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "ftn_period_spectrum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.POINTER(FtnExchange)]),
+    "ftn_exchange_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "ftn_exchange_error": (C.c_int, [C.POINTER(FtnExchange), _P]),
+    "ftn_exchange_alloc": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), _P]),
+    "ftn_exchange_open": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "ftn_exchange_close": (C.c_int, [_P]),
+    "ftn_exchange_free": (C.c_int, [_P]),
     "ftn_period_finalize": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, C.c_double, _P, _P, _P, _P]),
+                                      C.c_int, C.c_double, _P, _P, _P, _P, C.POINTER(FtnExchange)]),
     "ftn_desc_from_periods": (C.c_int, [C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(FtnDesc)]),
     "ftn_selector_px_bound": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
@@ -103,7 +119,7 @@ _SIGNATURES = {
                                               C.c_int, C.c_int, _P, _P, C.c_float, _P, C.c_size_t, _P, _P]),
     "ftn_period_finalize_stage_a": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, C.POINTER(FtnPlan), _P,
-                                              C.c_int, C.c_int, _P, C.c_size_t, _P, _P]),
+                                              C.c_int, C.c_int, _P, C.c_size_t, _P, _P, C.POINTER(FtnExchange)]),
     "ftn_residual_layernorm": (C.c_int, [_P, _P, _P, C.c_longlong, C.c_int, _P, _P, C.c_float, _P]),
     "ftn_head_forward": (C.c_int, [_P, C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_longlong,
                                    C.c_int, _P, C.c_longlong, _P, C.c_float, _P, _P, _P, _P]),

@@ -69,6 +69,8 @@ class FFTPeriodSelector(nn.Module):
         # batch-sharded multi-GPU: when set, the [F] batch sums are exchanged over this
         # process group so every rank selects identical periods
         self.shard_group = None
+        # dist.IpcExchange: the partial sums travel as peer writes into IPC-mapped buffers instead of a collective
+        self.shard_exchange = None
         self._pending = None
         self._lfi = torch.zeros(0, dtype=torch.long)
         self._lsp = torch.zeros(0, dtype=torch.long)
@@ -133,10 +135,20 @@ class FFTPeriodSelector(nn.Module):
         if xf.dtype != torch.float32:
             xf = xf.float()                                   # FFT is always >= fp32 (:92-94)
         xf = xf.contiguous()
-        med, psum = runtime.spectrum(xf)
+        xch = None
+        if self.shard_group is not None and self.shard_exchange is not None:
+            xch = self.shard_exchange.next_call(L // 2 + 1)        # this call's sequence number, same on every rank
+        med, psum = runtime.spectrum(xf, xch)
         b_total = B
         pre = None
-        if self.shard_group is not None:
+        if xch is not None:
+            # k_colsum has stored this rank's sums into every peer's buffer; the finalize workgroup waits for the
+            # peers' stores (bounded) while stage A runs beside it - no collective, nothing else for the host to do
+            if (max_unique or 0) > 0 or (log_base or 0.0) > 1.0:
+                raise NotImplementedError("TIMES_PERIOD_MAX_UNIQ / TIMES_PERIOD_BINNING are not supported with a "
+                                          "batch-sharded selector (shard_group): unset them or run unsharded")
+            b_total = B * self.shard_exchange.world
+        elif self.shard_group is not None:
             import torch.distributed as dist
 
             if (max_unique or 0) > 0 or (log_base or 0.0) > 1.0:
@@ -163,7 +175,7 @@ class FFTPeriodSelector(nn.Module):
             psum = parts
         sel = runtime.finalize(psum, b_total, med, L, self.k, self.pmax, self.min_period_threshold, adt,
                                max_unique or 0, log_base or 0.0,
-                               stage_a=None if stage_a is None else (xf,) + tuple(stage_a), pre=pre)
+                               stage_a=None if stage_a is None else (xf,) + tuple(stage_a), pre=pre, xch=xch)
         self._pending = sel
         return sel
 

@@ -92,8 +92,9 @@ class Selection:
         return self._host
 
 
-def spectrum(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """S1+S2 on the device: channel-median amplitude [B,F] and its fp64 batch sum [F]."""
+def spectrum(x: torch.Tensor, xch=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """S1+S2 on the device: channel-median amplitude [B,F] and its fp64 batch sum [F].  ``xch`` (a ``ctypes.byref`` of
+    an ``FtnExchange``): the sums are also stored into every rank's exchange buffer (``dist.IpcExchange``)."""
     lib = _lib.load()
     B, L, Cc = x.shape
     st = state(x.device)
@@ -101,7 +102,7 @@ def spectrum(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     med = torch.empty(B, Fb, dtype=torch.float32, device=x.device)
     psum = torch.empty(Fb, dtype=torch.float64, device=x.device)
     check(lib.ftn_period_spectrum(_ptr(x), B, L, Cc, _ptr(st.dft_table(L)), _ptr(med), _ptr(psum),
-                                  _stream(x.device)), "ftn_period_spectrum")
+                                  _stream(x.device), xch), "ftn_period_spectrum")
     return med, psum
 
 
@@ -145,14 +146,14 @@ def stage_a_only(x: torch.Tensor, plan: FtnPlan, wblob: torch.Tensor, k: int, pm
     ws = torch.empty(need, dtype=torch.uint8, device=x.device)
     check(lib.ftn_period_finalize_stage_a(None, 0, 0, None, B, L, int(k), int(pmax), int(min_thr), 0, 0, 0.0,
                                           None, None, None, _ptr(x), C.byref(plan), _ptr(wblob), mg, pxb, _ptr(ws),
-                                          ws.numel(), _stream(x.device), _ptr_or_null(range_flag)),
+                                          ws.numel(), _stream(x.device), _ptr_or_null(range_flag), None),
           "ftn_period_finalize_stage_a")
     return ws
 
 
 def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int, pmax: int,
              min_thr: int, act_dtype: int = 0, max_unique: int = 0, log_base: float = 0.0,
-             stage_a=None, pre=None) -> Selection:
+             stage_a=None, pre=None, xch=None) -> Selection:
     """S3-S5 on the device.  ``psum`` is [F] or [nparts, F] (multi-GPU partial sums); ``act_dtype`` 1 / 2
     applies the reference's bf16 / fp16 roundings of scores, amplitudes and weights.
 
@@ -164,7 +165,7 @@ def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int
     lib = _lib.load()
     B = med.shape[0]
     dev = med.device
-    nparts = 1 if psum.dim() == 1 else psum.shape[0]
+    nparts = 1 if psum.dim() == 1 else psum.shape[0]     # (with ``xch`` the parts are the exchange buffer's slots)
     desc = torch.empty(DESC_INTS, dtype=torch.int32, device=dev)
     amps = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
     wts = torch.empty(B, FTN_KMAX, dtype=torch.float32, device=dev)
@@ -185,13 +186,13 @@ def finalize(psum: torch.Tensor, b_total: int, med: torch.Tensor, L: int, k: int
                                               float(log_base or 0.0), _ptr(desc), _ptr(amps), _ptr(wts),
                                               _ptr(x) if pre is None else None,
                                               C.byref(plan), _ptr(wblob), sel.max_groups, sel.px_bound, _ptr(ws),
-                                              ws.numel(), _stream(dev), _ptr_or_null(range_flag)),
+                                              ws.numel(), _stream(dev), _ptr_or_null(range_flag), xch),
               "ftn_period_finalize_stage_a")
         sel.stage_a = (ws, x.data_ptr(), C.addressof(plan))
         return sel
     check(lib.ftn_period_finalize(_ptr(psum), nparts, int(b_total), _ptr(med), B, L, int(k), int(pmax),
                                   int(min_thr), int(act_dtype), int(max_unique or 0), float(log_base or 0.0), _ptr(desc),
-                                  _ptr(amps), _ptr(wts), _stream(dev)),
+                                  _ptr(amps), _ptr(wts), _stream(dev), xch),
           "ftn_period_finalize")
     return sel
 

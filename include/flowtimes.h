@@ -134,6 +134,36 @@ int ftn_inception_pack_weights(const FtnInceptionBlockWeights* block0, const Ftn
                                double bottleneck_ratio, int act, int engine, float* blob_host, size_t blob_floats,
                                FtnPlan* plan_out);
 
+/* ---- multi-GPU exchange of the [F] partial batch sums ------------------------------
+ * A batch-sharded TimesBlock needs one exchange per call: every rank's fp64 column sums of its channel-median
+ * spectrum, summed in rank order on every rank, so that all ranks select the same periods (:112 is a mean over the
+ * whole batch).  Instead of a collective launch each rank's k_colsum STORES its sums straight into a slot of every
+ * peer's exchange buffer - device memory of the peer, mapped here once with hipIpcOpenMemHandle, one hop over xGMI -
+ * followed by a sequence word; the finalize workgroup of ftn_period_finalize[_stage_a] waits (bounded) for the
+ * sequence words of all ranks in its OWN buffer and sums the slots in rank order.  No host work per call beyond
+ * passing this struct; no collective; deterministic.
+ *   slots[r]  rank r's exchange buffer as mapped into THIS process (slots[rank] = this rank's own hipMalloc'ed
+ *             buffer of ftn_exchange_bytes(world, F_cap) bytes, zeroed once before the first call)
+ *   seq       this call's sequence number: identical on every rank, starts at 1, +1 per exchange (the two halves of
+ *             the buffer alternate by seq & 1, so a rank one call ahead never overwrites what a peer still reads)
+ * A rank that does not hear from a peer within ~2 s writes an empty descriptor (the block becomes the identity) and
+ * sets the buffer's error word (ftn_exchange_error).  Not capturable in a HIP graph (seq is a launch argument). */
+#define FTN_XCHG_MAXWORLD 16
+typedef struct FtnExchange {
+  void* slots[FTN_XCHG_MAXWORLD];
+  int32_t world, rank, F_cap;
+  uint64_t seq;
+} FtnExchange;
+size_t ftn_exchange_bytes(int world, int F_cap);
+/* this rank's buffer on the current device (hipMalloc + zero) and its 64-byte hipIpcMemHandle_t, to be sent to the
+ * other ranks by whatever channel the host has; the other ranks' handles are opened with ftn_exchange_open */
+int ftn_exchange_alloc(int world, int F_cap, void** buf_out, void* handle64_out);
+int ftn_exchange_open(const void* handle64, void** mapped_out);
+int ftn_exchange_close(void* mapped);
+int ftn_exchange_free(void* buf);
+/* host-side read of the error word of this rank's own buffer (synchronises the stream): 0 = ok, 1 = a peer timed out */
+int ftn_exchange_error(const FtnExchange* xch, void* stream);
+
 /* ---- period selector: FFTPeriodSelector.forward (:64-159) ------------------- */
 /* bytes of the DFT twiddle table for window length L */
 size_t ftn_dft_table_bytes(int L);
@@ -144,8 +174,9 @@ int ftn_dft_table_init(void* table_dev, int L, void* stream);
  * Two kernels, bit-identical results: one workgroup per (row, 32-bin block), or - when a row's folded samples
  * and amplitude tile fit LDS (C <= 64, e.g. L = 336) and B >= 64 - one workgroup per row with x[b] resident in
  * LDS.  FTN_SEL_ROW=1 / 0 in the environment forces / forbids the second form. */
+/* xch (ABI 9; may be NULL): also publish psum to slot `rank` of every rank's exchange buffer (see FtnExchange). */
 int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* table_dev,
-                        float* med_dev, double* psum_dev, void* stream);
+                        float* med_dev, double* psum_dev, void* stream, const FtnExchange* xch);
 /* S3-S5 (:119-157, PeriodGrouper.group :513-557, softmax/scatter :992-1009).
  * psum: [nparts][F] partial batch sums (summed in index order; nparts>1 is the
  * multi-GPU exchange of SURVEY §8e), Btotal = global batch.  Writes the
@@ -161,7 +192,9 @@ int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* tab
 int ftn_period_finalize(const double* psum_dev, int nparts, int Btotal, const float* med_dev,
                         int B, int L, int k_periods, int pmax, int min_period_threshold, int act_dtype,
                         int max_unique, double log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
-                        void* stream);
+                        void* stream, const FtnExchange* xch);
+/* (xch != NULL: psum_dev / nparts are ignored - the partial sums are the world slots of this rank's exchange buffer
+ *  for sequence number xch->seq, which the kernel waits for) */
 /* Host-only: PeriodGrouper.group (:513-557, env flags unset) + conv tiling for
  * periods that come from somewhere else (stub selectors in the reference tests).
  * `periods` is a host array; `desc_host` is filled on the host. */
@@ -210,7 +243,8 @@ int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, int Btotal, 
                                 int k_periods, int pmax, int min_period_threshold, int act_dtype, int max_unique,
                                 double log_base, FtnDesc* desc_dev, float* amps_dev, float* weights_dev,
                                 const float* x_dev, const FtnPlan* plan, const float* wblob_dev, int max_groups,
-                                int px_bound, void* ws_dev, size_t ws_bytes, void* stream, int* range_flag);
+                                int px_bound, void* ws_dev, size_t ws_bytes, void* stream, int* range_flag,
+                                const FtnExchange* xch);
 /* The same call followed by the caller's per-block epilogue of TimesNet.forward (:2050-2058, eval mode):
  *   y = LayerNorm_C( x + (block(x) - x) ; gamma, beta, eps )
  * fused into the last kernel when d_model <= 64 (bottleneck mode), one extra in-place row pass otherwise. */

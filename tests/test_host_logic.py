@@ -213,14 +213,14 @@ def test_c_abi_rejects_bad_arguments_before_any_launch(ftn):
     fake = 1 << 20                                        # a non-null, 256-aligned "device pointer": never dereferenced
     # fused finalize + stage A: nothing to do (psum and x both NULL)
     rc = lib.ftn_period_finalize_stage_a(None, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake, fake, None,
-                                         C.byref(plan), fake, mg.value, pxb, fake, need, None, None)
+                                         C.byref(plan), fake, mg.value, pxb, fake, need, None, None, None)
     assert rc < 0 and b"nothing to do" in lib.ftn_last_error()
     # workspace too small
     rc = lib.ftn_period_finalize_stage_a(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake, fake, fake,
-                                         C.byref(plan), fake, mg.value, pxb, fake, need - 1, None, None)
+                                         C.byref(plan), fake, mg.value, pxb, fake, need - 1, None, None, None)
     assert rc < 0 and b"workspace" in lib.ftn_last_error()
     # misaligned amps / weights
-    rc = lib.ftn_period_finalize(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake + 4, fake, None)
+    rc = lib.ftn_period_finalize(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake + 4, fake, None, None)
     assert rc < 0 and b"aligned" in lib.ftn_last_error()
     # unknown flag bit / stage-A flag on a plan that is not a bottleneck block
     rc = lib.ftn_timesblock_forward(fake, fake, B, L, C.byref(plan), fake, fake, fake, mg.value, pxb, 0, 2, fake, need, None, None)
@@ -231,8 +231,18 @@ def test_c_abi_rejects_bad_arguments_before_any_launch(ftn):
     rc = lib.ftn_timesblock_forward(fake, fake, B, L, C.byref(plan1), fake, fake, fake, mg.value, pxb, 0, 1, fake, need1, None, None)
     assert rc < 0 and b"flags" in lib.ftn_last_error()
     rc = lib.ftn_period_finalize_stage_a(fake, 1, B, fake, B, L, 2, L, 1, 0, 0, 0.0, fake, fake, fake, fake,
-                                         C.byref(plan1), fake, mg.value, pxb, fake, max(need, need1), None, None)
+                                         C.byref(plan1), fake, mg.value, pxb, fake, max(need, need1), None, None, None)
     assert rc < 0 and b"bottleneck" in lib.ftn_last_error()
+    # multi-GPU exchange: a sequence number of 0, a rank outside the world or an unmapped slot are refused up front
+    xch = ftn.lib.FtnExchange()
+    xch.world, xch.rank, xch.F_cap, xch.seq = 2, 0, 64, 0
+    xch.slots[0] = fake
+    rc = lib.ftn_period_spectrum(fake, B, L, 16, fake, fake, fake, None, C.byref(xch))
+    assert rc < 0 and b"exchange" in lib.ftn_last_error()
+    xch.seq = 1
+    rc = lib.ftn_period_spectrum(fake, B, L, 16, fake, fake, fake, None, C.byref(xch))
+    assert rc < 0 and b"not mapped" in lib.ftn_last_error()
+    assert lib.ftn_exchange_bytes(2, 64) > 0 and lib.ftn_exchange_bytes(99, 64) == 0
 
 
 # ---- torch backend of the mirrors vs golden ----------------------------------
