@@ -188,9 +188,35 @@ def run_rank(args) -> None:
 
     if use_dist:
         import torch.distributed as dist
-        # FTN_EXCHANGE=ipc: the partial sums travel as peer stores into IPC-mapped buffers (dist.IpcExchange) instead
-        # of an all-gather launch
-        exchange = pkg.dist.IpcExchange(None, dev) if os.environ.get("FTN_EXCHANGE") == "ipc" else None
+        # The partial sums travel as peer stores into IPC-mapped buffers (dist.IpcExchange: no collective launch, no
+        # host work per call) unless FTN_EXCHANGE=rccl asks for the all-gather through the process group.  The IPC path
+        # is checked against the all-gather on the first batch - same periods, bit-equal rows on every rank - and the
+        # run falls back to the all-gather (and says so in the JSON line) if mapping, the check or a peer's timing fails.
+        exchange, exchange_note = None, "all-gather through the process group"
+        if os.environ.get("FTN_EXCHANGE", "ipc") == "ipc":
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                exchange = pkg.dist.IpcExchange(None, dev)
+                with torch.inference_mode():
+                    via_gather, via_ipc = pkg.dist.ShardedTimesBlock(blk), pkg.dist.ShardedTimesBlock(blk, exchange=exchange)
+                    y_g = via_gather(x, gather=False)
+                    p_g = blk.period_selector.last_selected_periods.tolist()
+                    y_i = via_ipc(x, gather=False)
+                    same = blk.period_selector.last_selected_periods.tolist() == p_g and bool(torch.equal(y_g, y_i))
+                    exchange.check()
+                if not same:
+                    ok.zero_()
+                    exchange_note = "all-gather through the process group (IPC check failed: results differ)"
+            except Exception as exc:                              # mapping refused, a peer timed out, ...
+                ok.zero_()
+                exchange_note = f"all-gather through the process group (IPC unavailable: {repr(exc)[:160]})"
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)             # all ranks take the same path
+            if int(ok.item()) == 0:
+                exchange = None
+                if "(" not in exchange_note:
+                    exchange_note += " (IPC failed on another rank)"
+            else:
+                exchange_note = "peer stores into IPC-mapped buffers (no collective), checked against the all-gather on the first batch"
         runner = pkg.dist.ShardedTimesBlock(blk, exchange=exchange)
         pending = []
 
@@ -218,7 +244,7 @@ def run_rank(args) -> None:
     else:
         step = lambda xx=None: blk(x if xx is None else xx)
         step_gather = None
-        exchange = None
+        exchange, exchange_note = None, "none" 
         drain = lambda: None
         barrier = lambda: None
 
@@ -508,9 +534,9 @@ def run_rank(args) -> None:
                        "windows_per_s": B_global / (elapsed / args.steps), "periods": periods, "groups": G,
                        "parallelism": (f"batch-shard x{dist_world} (torch.distributed world size, backend "
                                        f"{os.environ.get('FTN_BENCH_BACKEND', 'nccl')}"
-                                       f"{', partial sums by IPC peer stores' if os.environ.get('FTN_EXCHANGE') == 'ipc' else ''}"
+                                       f"; exchange of the [F] partial sums: {exchange_note}"
                                        f"{', REHEARSAL: ranks share GPUs' if os.environ.get('FTN_BENCH_SHARE_GPU') == '1' else ''}): one "
-                                       "all-gather of [F] fp64 partial sums per step, outputs stay sharded"
+                                       "exchange of [F] fp64 partial sums per step, outputs stay sharded"
                                        if use_dist else "single")},
             "roofline": {"bound": "mfma", "kernel": STAGES[dom], "achieved": achieved, "peak": peak_tf,
                          "unit": "TFLOP/s", "frac": achieved / peak_tf, "traffic": traffic, "traffic_source": traffic_source,

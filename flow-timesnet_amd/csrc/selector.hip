@@ -737,7 +737,11 @@ extern "C" int ftn_exchange_alloc(int world, int F_cap, void** buf_out, void* ha
   FTN_CHECK_ARG(n > 0 && buf_out && handle64_out, "ftn_exchange_alloc: world=%d F_cap=%d", world, F_cap);
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, n);
+  // uncached device memory where the runtime offers it (what RCCL uses for words that GPUs exchange inside running
+  // kernels): every access goes to memory, whichever GPU issues it; plain hipMalloc otherwise (the kernels use
+  // system-scope loads / stores either way)
+  hipError_t e = hipExtMallocWithFlags(&p, n, hipDeviceMallocUncached);
+  if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; e = hipMalloc(&p, n); }
   if (e == hipSuccess) e = hipMemset(p, 0, n);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64_out, p);
