@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include "ftn_common.h"
 #include "ftn_mlp.h"
+#include "ftn_out.h"
 
 #define NPXU 4  // 16-pixel units per wave in the pointwise / conv kernels
 
@@ -1910,75 +1911,7 @@ __global__ void k_embed(const float* __restrict__ x, float* __restrict__ out, in
 // ascending order (same summation order as the reference; deterministic, no
 // atomics); the tail pixels t >= L of every grid are never touched.  HBM/L2-bound:
 // reads m' and r once, x once, writes y once.
-struct OutArgs {
-  const float* x;
-  float* y;
-  const float* m;        // [N][KM] conv output of block 2
-  const float* R;        // [N][CP]
-  const float* W;        // w_out2 [CP][KM] row-major (IDENT: unused, KM == CP)
-  const float* bias;
-  const float* wts;      // [B][FTN_KMAX]
-  const FtnDesc* desc;
-  int B, L, C, CP, KM;
-  const float* ln_g;     // optional fused epilogue (FAST path): y = LayerNorm_C(x + ((x + comb) - x)), the
-  const float* ln_b;     // per-block residual + shared LayerNorm of TimesNet.forward (reference :2050-2058)
-  float ln_eps;
-  int r_keeps_x;         // R holds res2(g) + b, not res2(g) + b - x: y = x + (sum_g w_g (e_g + R_g) - (sum_g w_g) x).  Stage C then
-                         // never re-reads x (93 MB of its 286 MB of fetches at the bench shape); fp32 activations only -
-                         // for half inputs every per-group delta is rounded, so x must come off before the weighting
-  int act_dtype;         // 1 bf16 / 2 fp16 input: the reference rounds every per-group delta, each weighted
-                         // term, their sum and x + sum to the input dtype (:1068-1069, :1092, :818); 0 = fp32
-  int* range_flag;       // f16x2 engine: set when an output value is not finite (ftn_common.h); may be null
-  int r_summed;          // position-major stage C (k_mlp_pos): R is ONE [B*L][CP] tensor that already holds
-                         // sum_g w_g (res2(g_g) + b) per window position: y = x + (sum_g w_g e_g + R - (sum_g w_g) x)
-};
-
-__device__ __forceinline__ f4 rnd_act4(f4 v, int act_dtype) {
-  if (act_dtype == 1) { v.x = (float)(__bf16)v.x; v.y = (float)(__bf16)v.y; v.z = (float)(__bf16)v.z; v.w = (float)(__bf16)v.w; }
-  else if (act_dtype == 2) { v.x = (float)(_Float16)v.x; v.y = (float)(_Float16)v.y; v.z = (float)(_Float16)v.z; v.w = (float)(_Float16)v.w; }
-  return v;
-}
-
-// LayerNorm over the channel axis of an MFMA D-layout tile set: v[o][u][r] is channel 16o+4q+r of the
-// pixel (u, lane&15); the four q lane-groups of a pixel are combined with two xor-shuffles.
-// Two-pass (mean, then centred sum of squares), biased variance, as nn.LayerNorm.
-template <int NO, int NPX>
-__device__ __forceinline__ void ln_tiles(f4 (&v)[NO][NPX], int n_ot, int C, int q, const float* __restrict__ g,
-                                         const float* __restrict__ b, float eps) {
-  const float inv = 1.0f / (float)C;
-#pragma unroll
-  for (int u = 0; u < NPX; ++u) {
-    float s = 0.f;
-#pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (o < n_ot && 16 * o + 4 * q + r < C) s += v[o][u][r];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    const float mean = s * inv;
-    float ss = 0.f;
-#pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (o < n_ot && 16 * o + 4 * q + r < C) {
-          const float dv = v[o][u][r] - mean;
-          ss += dv * dv;
-        }
-    ss += __shfl_xor(ss, 16);
-    ss += __shfl_xor(ss, 32);
-    const float rstd = 1.0f / sqrtf(ss * inv + eps);
-#pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (o < n_ot && 16 * o + 4 * q + r < C) {
-          const int ch = 16 * o + 4 * q + r;
-          v[o][u][r] = (v[o][u][r] - mean) * rstd * g[ch] + b[ch];
-        }
-  }
-}
+// (OutArgs, rnd_act4 and ln_tiles live in ftn_out.h, shared with stage_out.hip)
 
 // Standalone form of the same epilogue for the shapes k_out does not fuse (d_model > 64) and for
 // blocks that return x unchanged: out = LayerNorm_C(x + (nw - x)); one wave per row, in place allowed.
@@ -2860,8 +2793,10 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // D: m' = conv(a')
     ca.in = buf0; ca.bt_L = 0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
+    // stage E on the 16-bit pipe (k_out_h): the second conv then leaves m' as activation pieces
+    const bool out_h = mlp_bf && ftn_out_h_enabled() != 0 && pl->w_out2fb != 0 && nsplit >= 2 && act_dtype == 0 && CA <= 64 && CP <= 64;
     if (use_bf) {
-      cb.in = (const __bf16*)buf0; cb.bt_L = 0; cb.bias = wb + (h2 ? pl->b_conv2s : pl->b_conv2); cb.out_p3 = 0;
+      cb.in = (const __bf16*)buf0; cb.bt_L = 0; cb.bias = wb + (h2 ? pl->b_conv2s : pl->b_conv2); cb.out_p3 = out_h ? 1 : 0;
       for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf2[k]); cb.inv[k] = h2 ? 1.0f / pl->sc_conv2[k] : 1.0f; }
       if ((rc = launch_conv_bf(cb, bfg, B, max_groups, nsplit, st, rows_est))) return rc;
     } else if ((rc = launch_conv(ca, B, L, max_groups, st))) return rc;
@@ -2877,6 +2812,11 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     if (fast) { oa.ln_g = ln_g; oa.ln_b = ln_b; oa.ln_eps = ln_eps; ln_g = nullptr; }   // fused epilogue
     // FAST path: 16 pixels per wave (3 waves/SIMD; with 32 the kernel needs > 256 registers -> 1 wave/SIMD)
     const unsigned nblk_fast = (unsigned)(((long long)B * L + 63) / 64);
+    if (out_h) {
+      oa.mh = (const __bf16*)buf1; oa.Wf = (const __bf16*)(wb + pl->w_out2fb);
+      oa.bias = wb + (h2 ? pl->b_out2s : pl->b_out2); oa.inv_out2 = h2 ? 1.0f / pl->sc_out2 : 1.0f;
+      if ((rc = ftn_launch_out_h(oa, ACT, nsplit, xvec && yvec, st))) return rc;
+    } else
     if (xvec && yvec && fast) hipLaunchKernelGGL((k_out<ACT, true, false, true, 1>), dim3(nblk_fast), dim3(256), 0, st, oa);
     else if (xvec && yvec) hipLaunchKernelGGL((k_out<ACT, true, false, false>), dim3(nblk_out), dim3(256), 0, st, oa);
     else if (fast) hipLaunchKernelGGL((k_out<ACT, false, false, true, 1>), dim3(nblk_fast), dim3(256), 0, st, oa);

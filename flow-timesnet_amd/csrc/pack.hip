@@ -201,7 +201,7 @@ static int pack_impl(const FtnInceptionBlockWeights* blk0, const FtnInceptionBlo
   const FtnInceptionBlockWeights* B[2] = {blk0, blk2};
   const int cins[2] = {C, F}, couts[2] = {F, C}, cinPs[2] = {CP, FP}, coutPs[2] = {FP, CP};
   for (int j = 0; j < FTN_MAXBR; ++j) plan->sc_conv1[j] = plan->sc_conv2[j] = 1.0f;
-  plan->sc_out1 = plan->sc_res1 = plan->sc_a2 = plan->sc_r2 = 1.0f;
+  plan->sc_out1 = plan->sc_res1 = plan->sc_a2 = plan->sc_r2 = plan->sc_out2 = 1.0f;
 
   auto res = [&](int bi, int32_t* flag, int64_t* w_off, int64_t* b_off, Mat* Wm, dvec* bv) -> int {
     const int cin = cins[bi], cout = couts[bi], cinP = cinPs[bi], coutP = coutPs[bi];
@@ -352,6 +352,23 @@ static int pack_impl(const FtnInceptionBlockWeights* blk0, const FtnInceptionBlo
         for (int o = 0; o < n_ot; ++o) frag_split(&Wcs, o, cols, h2, base + (size_t)(k++) * 3 * 512);
       }
       plan->w_cfragbf = blob.add16(cfb); plan->cfragbf_per_chunk = perb;
+      // stage E (k_out_h): w_out2 [CP][CA] as K=32 fragments, row tile major
+      Mat Wo2 = fb[1].W_out;
+      if (h2) {
+        const double s5 = pow2_scale(Wo2.v.data(), Wo2.v.size());
+        plan->sc_out2 = (float)s5;
+        for (double& v : Wo2.v) v *= s5;
+        dvec b2s(CP);
+        for (int i = 0; i < CP; ++i) b2s[i] = fb[1].b_out[i] * s5;
+        plan->b_out2s = blob.add(b2s);
+      }
+      std::vector<uint16_t> ofb((size_t)(CP / 16) * nsKM * 3 * 512, 0);
+      {
+        int k = 0, cols[32];
+        for (int o = 0; o < CP / 16; ++o)
+          for (int s = 0; s < nsKM; ++s) { for (int c = 0; c < 32; ++c) cols[c] = 32 * s + c; frag_split(&Wo2, o, cols, h2, ofb.data() + (size_t)(k++) * 3 * 512); }
+      }
+      plan->w_out2fb = blob.add16(ofb);
     }
   } else {
     plan->mode = 1; plan->MP = 0; plan->nbr = 1;

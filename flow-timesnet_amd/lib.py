@@ -13,7 +13,7 @@ from typing import Optional
 
 FTN_KMAX = 16
 FTN_MAXBR = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "csrc" / "libflowtimes_hip.so"
@@ -74,6 +74,7 @@ class FtnPlan(C.Structure):
         ("b_c2s", C.c_int64),
         ("sc_conv1", C.c_float * FTN_MAXBR), ("sc_conv2", C.c_float * FTN_MAXBR),
         ("sc_out1", C.c_float), ("sc_res1", C.c_float), ("sc_a2", C.c_float), ("sc_r2", C.c_float),
+        ("w_out2fb", C.c_int64), ("b_out2s", C.c_int64), ("sc_out2", C.c_float), ("reserved0", C.c_int32),
         ("total_floats", C.c_int64),
     ]
 

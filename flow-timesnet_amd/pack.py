@@ -370,7 +370,7 @@ def pack_inception_numpy(
     nk = len(ks)
     for j in range(FTN_MAXBR):
         plan.sc_conv1[j] = plan.sc_conv2[j] = 1.0
-    plan.sc_out1 = plan.sc_res1 = plan.sc_a2 = plan.sc_r2 = 1.0
+    plan.sc_out1 = plan.sc_res1 = plan.sc_a2 = plan.sc_r2 = plan.sc_out2 = 1.0
 
     def res(blk, cin, cout, cinP, coutP):
         key = f"{blk}.res_proj.weight"
@@ -468,7 +468,7 @@ def pack_inception_numpy(
             plan.w_convbf2[j] = blob.add(convs_bf[nk + j])
         for j in range(FTN_MAXBR):
             plan.sc_conv1[j] = plan.sc_conv2[j] = 1.0
-        plan.sc_out1 = plan.sc_res1 = plan.sc_a2 = plan.sc_r2 = 1.0
+        plan.sc_out1 = plan.sc_res1 = plan.sc_a2 = plan.sc_r2 = plan.sc_out2 = 1.0
         if h2:
             # biases prescaled like their weight matrices: the accumulators start from them (flowtimes.h FtnPlan)
             s1 = np.repeat(np.array(conv_sc[:nk]), MP)
@@ -493,6 +493,16 @@ def pack_inception_numpy(
                 plan.w_cfragbf = blob.add(_pack_cfrag_bf(W_out1.astype(np.float32), Wr1.astype(np.float32),
                                                          Wc.astype(np.float32), FP, nsKM, nsCP, n_ot))
             plan.cfragbf_per_chunk = 2 * nsKM + 2 * nsCP + n_ot
+            # stage E (k_out_h): w_out2 [CP][CA] as K=32 fragments, row tile major
+            frag, bits, Wo2 = _frag_bf, _bf16_bits_as_f32, W_out2
+            if h2:
+                plan.sc_out2 = pow2_scale(W_out2)
+                plan.b_out2s = blob.add(b_out2 * plan.sc_out2)
+                frag, bits, Wo2 = _frag_h2, _f16_bits_as_f32, W_out2 * plan.sc_out2
+            Wo2 = Wo2.astype(np.float32)
+            ofb = np.stack([frag(Wo2, o, list(range(32 * s_, 32 * s_ + 32)))
+                            for o in range(CP // 16) for s_ in range(nsKM)], 0)
+            plan.w_out2fb = blob.add(bits(ofb if h2 else ofb.astype(np.float32)))
     else:
         plan.mode = 1
         plan.MP, plan.nbr = 0, 1

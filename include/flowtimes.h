@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTN_ABI_VERSION 9
+#define FTN_ABI_VERSION 10
 #define FTN_KMAX 16      /* max period candidates / groups per block call        */
 #define FTN_MAXBR 8      /* max kernels in kernel_set                             */
 
@@ -103,6 +103,12 @@ typedef struct FtnPlan {
   int64_t b_conv1s, b_conv2s, b_out1s, b_res1s, b_c2s;
   float sc_conv1[FTN_MAXBR], sc_conv2[FTN_MAXBR];
   float sc_out1, sc_res1, sc_a2, sc_r2;   /* W_out1, W_res1, W_in2 rows of w_c2, W_res2 rows of w_c2 */
+  /* split engines, stage E on the 16-bit matrix pipe (the shapes that carry w_cfragbf): w_out2 as K=32 fragments of
+   * three pieces, [CP/16 row tiles][ceil(nbr*MP/32) slabs][piece][lane][8] (0 = absent); f16x2: of sc_out2 w_out2,
+   * with b_out2s = sc_out2 b_out2 */
+  int64_t w_out2fb, b_out2s;
+  float sc_out2;
+  int32_t reserved0;
   int64_t total_floats;
 } FtnPlan;
 

@@ -36,9 +36,9 @@ def test_library_exports_every_declared_symbol(ftn):
 
 
 def test_struct_sizes_match_header(ftn):
-    # FtnDesc: 4 + 6*16 + 17 + 4*16 + 17 ints ; FtnPlan: 26 ints + 33 int64 + 2 ints + 1 int64
+    # FtnDesc: 4 + 6*16 + 17 + 4*16 + 17 ints ; FtnPlan: ... + (w_out2fb, b_out2s) + (sc_out2, reserved0) + total_floats
     assert ctypes.sizeof(ftn.lib.FtnDesc) == 4 * (4 + 6 * 16 + 17 + 4 * 16 + 17)
-    assert ctypes.sizeof(ftn.lib.FtnPlan) == 4 * 26 + 8 * 33 + 4 * 2 + 8 * 16 + 4 * 2 + 8 + 8 * 5 + 4 * 20 + 8
+    assert ctypes.sizeof(ftn.lib.FtnPlan) == 4 * 26 + 8 * 33 + 4 * 2 + 8 * 16 + 4 * 2 + 8 + 8 * 5 + 4 * 20 + 8 * 2 + 4 * 2 + 8
 
 
 @pytest.mark.parametrize("periods,L", [([24, 168, 7, 24, 0, 500], 336), ([4, 4, 8, 4], 25), ([47, 24, 2], 48),
