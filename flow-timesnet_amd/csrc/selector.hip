@@ -309,6 +309,9 @@ __global__ __launch_bounds__(256) void k_spectrum(const float* __restrict__ x, i
         ac[k] = pc[k * sT]; as[k] = ps[k * sT]; be[k] = xv + xp; bo[k] = xv - xp;
       }
       pc += 8 * sT; ps += 8 * sT; px += 8 * sX; pp -= 8 * sX;
+      // (complete before the loop is entered: see k_spectrum_rowq)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(ac[k]), "+v"(as[k]), "+v"(be[k]), "+v"(bo[k]));
     }
     for (int it = 0; it < nint; ++it) {
       float an[8], sn[8], en[8], on[8];
@@ -470,6 +473,12 @@ __global__ __launch_bounds__(1024) void k_spectrum_row(const float* __restrict__
     if (nblk > 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { ac[k] = pc[k * sT]; as[k] = ps[k * sT]; }
+      // the first block's twiddles are complete before the loop is entered: hipcc's wait-count pass otherwise carries
+      // "ac / as may still be in flight" round the back edge and puts an s_waitcnt vmcnt(0) in front of the second MFMA
+      // of EVERY iteration - i.e. behind the loads just issued for the next block, which undoes the pipelining
+      // (MFMA phase at 55 % of the pipe's rate)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(ac[k]), "+v"(as[k]));
     }
     for (int it = 0; it < nblk; ++it) {
       float an[8], sn[8], be[8], bo[8];
@@ -531,21 +540,30 @@ __global__ __launch_bounds__(1024) void k_spectrum_row(const float* __restrict__
 // Half the fp32 MFMAs of k_spectrum_row - the pipe that kernel is bound by - for two more adds per sample.  A
 // wave takes (parity, 32-bin block of that parity, channel tile).  Not bit-identical to the other two kernels
 // (the four-term sums round differently, at the 1e-7 level); ranks of a sharded batch all take the same path.
-__global__ __launch_bounds__(1024) void k_spectrum_rowq(const float* __restrict__ x, int B, int L, int C,
+// Channel-tiled form (amp_g != nullptr; d_model > 64, where four fold planes of the whole row no longer fit LDS):
+// workgroup (b, blockIdx.y) folds and transforms channels [ctile * blockIdx.y, + ctile) only and writes its
+// amplitudes to amp_g [B][F][Ctot]; the medians over all channels are then taken by k_median_rows.
+__global__ __launch_bounds__(1024) void k_spectrum_rowq(const float* __restrict__ x, int B, int L, int Ctot,
                                                         const float* __restrict__ qtab, int F, int QP, int FQ,
-                                                        int amp_rows, float* __restrict__ med) {
+                                                        int amp_rows, float* __restrict__ med, int ctile,
+                                                        float* __restrict__ amp_g) {
   extern __shared__ __attribute__((aligned(16))) float lds_row[];
   const int H = L >> 1, Q = L >> 2;
+  // (fused form: gridDim.x = B; tiled form: gridDim = (tiles, B), a row's tiles dispatched together so that what is in
+  // flight at any time covers whole rows of x, i.e. every memory channel)
+  const int tiled = amp_g != nullptr ? 1 : 0;
+  const int c_base = tiled ? (int)blockIdx.x * ctile : 0;
+  const int C = Ctot - c_base < ctile ? Ctot - c_base : ctile;      // channels of this workgroup
   const int nct = (C + 31) >> 5, CP = nct * 32, CS = C + 1;
   const size_t plane = (size_t)QP * CP;
   float* __restrict__ fold = lds_row;                  // [4][QP][CP]: ee, eo, oe, oo
   float* __restrict__ amp = lds_row + 4 * plane;       // [amp_rows][CS]
-  const int b = blockIdx.x;
+  const int b = tiled ? blockIdx.y : blockIdx.x;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const float* __restrict__ xb = x + (size_t)b * L * C;
+  const float* __restrict__ xb = x + (size_t)b * L * Ctot + c_base;
   {
-    const bool vec = (C & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+    const bool vec = (Ctot & 3) == 0 && (((uintptr_t)x) & 15) == 0;
     const int cw = vec ? 4 : 1, cn = CP / cw, total = QP * cn;
     for (int e0 = tid; e0 < total; e0 += 2 * nthr) {
       f4 x0[2], x1[2], x2[2], x3[2];                   // x[tau], x[L - tau], x[H - tau], x[H + tau]
@@ -560,13 +578,13 @@ __global__ __launch_bounds__(1024) void k_spectrum_rowq(const float* __restrict_
         if (ok) {
           const int t = tau[u];
           if (vec) {
-            x0[u] = *(const f4*)(xb + (size_t)t * C + c[u]);
-            if (t > 0) x1[u] = *(const f4*)(xb + (size_t)(L - t) * C + c[u]);
-            if (t < Q) { x2[u] = *(const f4*)(xb + (size_t)(H - t) * C + c[u]); if (t > 0) x3[u] = *(const f4*)(xb + (size_t)(H + t) * C + c[u]); }
+            x0[u] = *(const f4*)(xb + (size_t)t * Ctot + c[u]);
+            if (t > 0) x1[u] = *(const f4*)(xb + (size_t)(L - t) * Ctot + c[u]);
+            if (t < Q) { x2[u] = *(const f4*)(xb + (size_t)(H - t) * Ctot + c[u]); if (t > 0) x3[u] = *(const f4*)(xb + (size_t)(H + t) * Ctot + c[u]); }
           } else {
-            x0[u].x = xb[(size_t)t * C + c[u]];
-            if (t > 0) x1[u].x = xb[(size_t)(L - t) * C + c[u]];
-            if (t < Q) { x2[u].x = xb[(size_t)(H - t) * C + c[u]]; if (t > 0) x3[u].x = xb[(size_t)(H + t) * C + c[u]]; }
+            x0[u].x = xb[(size_t)t * Ctot + c[u]];
+            if (t > 0) x1[u].x = xb[(size_t)(L - t) * Ctot + c[u]];
+            if (t < Q) { x2[u].x = xb[(size_t)(H - t) * Ctot + c[u]]; if (t > 0) x3[u].x = xb[(size_t)(H + t) * Ctot + c[u]]; }
           }
         }
       }
@@ -613,6 +631,12 @@ __global__ __launch_bounds__(1024) void k_spectrum_rowq(const float* __restrict_
     if (nblk > 0) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { ac[k] = pc[k * sT]; as[k] = ps[k * sT]; }
+      // the first block's twiddles are complete before the loop is entered: hipcc's wait-count pass otherwise carries
+      // "ac / as may still be in flight" round the back edge and puts an s_waitcnt vmcnt(0) in front of the second MFMA
+      // of EVERY iteration - i.e. behind the loads just issued for the next block, which undoes the pipelining
+      // (MFMA phase at 55 % of the pipe's rate)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(ac[k]), "+v"(as[k]));
     }
     for (int it = 0; it < nblk; ++it) {
       float an[8], sn[8], be[8], bo[8];
@@ -639,7 +663,13 @@ __global__ __launch_bounds__(1024) void k_spectrum_rowq(const float* __restrict_
       re = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[(size_t)ks * sT], pe[ks * sX], re, 0, 0, 0);
       im = __builtin_amdgcn_mfma_f32_32x32x2f32(ps[(size_t)ks * sT], po[ks * sX], im, 0, 0, 0);
     }
-    if (c < C) {
+    if (c < C && amp_g != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int f = 2 * (m0 + (r & 3) + 8 * (r >> 2) + 4 * h) + odd;
+        if (f < F) amp_g[((size_t)b * F + f) * Ctot + c_base + c] = hypotf(re[r], im[r]);
+      }
+    } else if (c < C) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int fi = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -647,6 +677,7 @@ __global__ __launch_bounds__(1024) void k_spectrum_rowq(const float* __restrict_
       }
     }
   }
+  if (amp_g != nullptr) return;
   __syncthreads();
   const int nw = nthr >> 6;
   for (int fb = wave * 8; fb < F; fb += nw * 8) {       // rows fb .. fb + 7 < amp_rows
@@ -657,6 +688,80 @@ __global__ __launch_bounds__(1024) void k_spectrum_rowq(const float* __restrict_
       for (int r = 0; r < 8; ++r)
         if (fb + r < F) med[(size_t)b * F + fb + r] = m[r];
     }
+  }
+}
+
+// bitonic_step_med3 with the direction flipped (the upper half of a 128-element network's k = 64 stage)
+template <int K, int J, int NR>
+__device__ __forceinline__ void bitonic_step_med3_desc(float (&v)[NR], int lane) {
+  const bool keepmin = !(((lane & K) == 0) == ((lane & J) == 0));
+  const float sel = keepmin ? -INFINITY : INFINITY;
+  float o[NR];
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (J < 16) asm volatile("s_nop 1");
+#pragma unroll
+  for (int r = 0; r < NR; ++r) o[r] = lane_xor_raw<J>(v[r]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], o[r], sel);
+}
+
+// Lower median of NR rows of 64 < C <= 128 values: the 28-step bitonic network on two registers per lane and row
+// (elements lane and 64 + lane), every lane exchange a raw DPP move + one v_med3 as in wave_lower_median_rows.
+template <int NR>
+__device__ __forceinline__ void wave_lower_median128_rows(const float* __restrict__ base, size_t stride, int C, int lane,
+                                                          float (&m)[NR]) {
+  float a[NR], b[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    a[r] = base[r * stride + lane];                               // C > 64
+    b[r] = 64 + lane < C ? base[r * stride + 64 + lane] : INFINITY;
+  }
+#define FTN_BOTH(K, J) bitonic_step_med3<K, J, NR>(a, lane); bitonic_step_med3<K, J, NR>(b, lane)
+  FTN_BOTH(2, 1);
+  FTN_BOTH(4, 2); FTN_BOTH(4, 1);
+  FTN_BOTH(8, 4); FTN_BOTH(8, 2); FTN_BOTH(8, 1);
+  FTN_BOTH(16, 8); FTN_BOTH(16, 4); FTN_BOTH(16, 2); FTN_BOTH(16, 1);
+  FTN_BOTH(32, 16); FTN_BOTH(32, 8); FTN_BOTH(32, 4); FTN_BOTH(32, 2); FTN_BOTH(32, 1);
+  // k = 64: elements 0..63 ascending, 64..127 descending
+#define FTN_UPDOWN(J) bitonic_step_med3<64, J, NR>(a, lane); bitonic_step_med3_desc<64, J, NR>(b, lane)
+  FTN_UPDOWN(32); FTN_UPDOWN(16); FTN_UPDOWN(8); FTN_UPDOWN(4); FTN_UPDOWN(2); FTN_UPDOWN(1);
+#undef FTN_UPDOWN
+  // k = 128, ascending everywhere: distance 64 is the register pair, then the lane distances
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { const float lo = fminf(a[r], b[r]), hi = fmaxf(a[r], b[r]); a[r] = lo; b[r] = hi; }
+  FTN_BOTH(64, 32); FTN_BOTH(64, 16); FTN_BOTH(64, 8); FTN_BOTH(64, 4); FTN_BOTH(64, 2); FTN_BOTH(64, 1);
+#undef FTN_BOTH
+  const int t = (C - 1) >> 1;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) m[r] = t < 64 ? __shfl(a[r], t) : __shfl(b[r], t - 64);
+}
+
+// Lower median over the channels of amp_g [rows][C], 64 < C <= 128 (the channel-tiled k_spectrum_rowq): four rows
+// per wave.
+__global__ __launch_bounds__(256) void k_median_rows(const float* __restrict__ amp_g, long long rows, int C,
+                                                     float* __restrict__ med) {
+  const int lane = threadIdx.x & 63;
+  const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  if (r0 >= rows) return;
+  // a ragged last wave re-reads the last row (never written twice: the store below is guarded)
+  const long long last = rows - 1;
+  const float* __restrict__ base = amp_g + (size_t)r0 * C;
+  float m[4];
+  if (r0 + 3 <= last) wave_lower_median128_rows<4>(base, (size_t)C, C, lane, m);
+  else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float one[1];
+      const long long rr = r0 + r <= last ? r0 + r : last;
+      wave_lower_median128_rows<1>(amp_g + (size_t)rr * C, (size_t)C, C, lane, one);
+      m[r] = one[0];
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r0 + r <= last) med[r0 + r] = m[r];
   }
 }
 
@@ -782,8 +887,22 @@ extern "C" int ftn_exchange_error(const FtnExchange* xch, void* stream) {
   return v;
 }
 
+// channel-tiled k_spectrum_rowq: 64 < C <= 128 (k_median_rows' network), the four fold planes of a 32-channel tile fit
+// LDS, <= 16 waves; batch rows ride on gridDim.y
+static bool qtile_fits(int L, int C) {
+  if (!qfold_ok(L) || C <= 64 || C > 128) return false;
+  const int QP = qfold_qp(L), FQ = qfold_fq(L);
+  return 2 * (FQ / 32) <= 16 && (size_t)4 * QP * 32 * sizeof(float) <= 160 * 1024;
+}
+
+extern "C" size_t ftn_period_spectrum_scratch_bytes(int B, int L, int C) {
+  if (B < 1 || B > 65535 || L < 2 || C < 1 || !qtile_fits(L, C)) return 0;
+  return (size_t)B * (L / 2 + 1) * C * sizeof(float);
+}
+
 extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* table_dev,
-                                   float* med_dev, double* psum_dev, void* stream, const FtnExchange* xch) {
+                                   float* med_dev, double* psum_dev, void* stream, const FtnExchange* xch,
+                                   void* scratch_dev) {
   FTN_CHECK_ARG(x_dev && table_dev && med_dev && psum_dev, "ftn_period_spectrum: null pointer");
   FTN_CHECK_ARG(xch == nullptr || xch_ok(xch, L / 2 + 1), "ftn_period_spectrum: bad exchange (world / rank / seq / F_cap)");
   FTN_CHECK_ARG(xch == nullptr || xch_mapped(xch), "ftn_period_spectrum: an exchange slot is not mapped");
@@ -810,11 +929,22 @@ extern "C" int ftn_period_spectrum(const float* x_dev, int B, int L, int C, cons
   const int amp_rows = ((2 * FQ > FPAD ? 2 * FQ : FPAD) + 7) & ~7;
   const size_t lds_q = (size_t)4 * QP * nct * 32 * sizeof(float) + (size_t)amp_rows * (C + 1) * sizeof(float);
   const bool q_fits = qfold_ok(L) && C <= 64 && 2 * (FQ / 32) * nct <= 16 && lds_q <= 160 * 1024;
-  if (q_fits && (row_mode == 2 || (row_mode < 0 && B >= 64))) {
+  if (scratch_dev != nullptr && B <= 65535 && qtile_fits(L, C) && row_mode != 0 && row_mode != 1) {
+    // d_model > 64: (row, 32-channel tile) workgroups, amplitudes through the caller's scratch, medians in a second launch
+    const size_t lds_t = (size_t)4 * QP * 32 * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)k_spectrum_rowq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+    if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_spectrum_rowq): %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(k_spectrum_rowq, dim3((unsigned)nct, (unsigned)B), dim3(64 * 2 * (FQ / 32)), lds_t, (hipStream_t)stream, x_dev,
+                       B, L, C, (const float*)table_dev + (size_t)2 * L * FPAD, F, QP, FQ, 0, med_dev, 32, (float*)scratch_dev);
+    FTN_CHECK_LAUNCH();
+    const long long rows = (long long)B * F;
+    hipLaunchKernelGGL(k_median_rows, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)scratch_dev, rows, C, med_dev);
+  } else if (q_fits && (row_mode == 2 || (row_mode < 0 && B >= 64))) {
     hipError_t e = hipFuncSetAttribute((const void*)k_spectrum_rowq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
     if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_spectrum_rowq): %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(k_spectrum_rowq, dim3((unsigned)B), dim3(64 * 2 * (FQ / 32) * nct), lds_q, (hipStream_t)stream, x_dev, B, L,
-                       C, (const float*)table_dev + (size_t)2 * L * FPAD, F, QP, FQ, amp_rows, med_dev);
+                       C, (const float*)table_dev + (size_t)2 * L * FPAD, F, QP, FQ, amp_rows, med_dev, C, (float*)nullptr);
   } else if (row_fits && (row_mode == 1 || (row_mode < 0 && B >= 64))) {
     hipError_t e = hipFuncSetAttribute((const void*)k_spectrum_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);
     if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_spectrum_row): %s", hipGetErrorString(e)); return (int)e; }

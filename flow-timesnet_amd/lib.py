@@ -101,7 +101,8 @@ _SIGNATURES = {
                                              C.c_double, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(FtnPlan)]),
     "ftn_dft_table_bytes": (C.c_size_t, [C.c_int]),
     "ftn_dft_table_init": (C.c_int, [_P, C.c_int, _P]),
-    "ftn_period_spectrum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.POINTER(FtnExchange)]),
+    "ftn_period_spectrum_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ftn_period_spectrum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.POINTER(FtnExchange), _P]),
     "ftn_exchange_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "ftn_exchange_error": (C.c_int, [C.POINTER(FtnExchange), _P]),
     "ftn_exchange_alloc": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p), _P]),

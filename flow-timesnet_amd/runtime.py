@@ -101,8 +101,10 @@ def spectrum(x: torch.Tensor, xch=None) -> Tuple[torch.Tensor, torch.Tensor]:
     Fb = L // 2 + 1
     med = torch.empty(B, Fb, dtype=torch.float32, device=x.device)
     psum = torch.empty(Fb, dtype=torch.float64, device=x.device)
+    nscr = int(lib.ftn_period_spectrum_scratch_bytes(B, L, Cc))      # > 0: the channel-tiled form of d_model > 64
+    scratch = torch.empty(nscr, dtype=torch.uint8, device=x.device) if nscr else None
     check(lib.ftn_period_spectrum(_ptr(x), B, L, Cc, _ptr(st.dft_table(L)), _ptr(med), _ptr(psum),
-                                  _stream(x.device), xch), "ftn_period_spectrum")
+                                  _stream(x.device), xch, _ptr_or_null(scratch)), "ftn_period_spectrum")
     return med, psum
 
 

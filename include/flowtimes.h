@@ -181,8 +181,13 @@ int ftn_dft_table_init(void* table_dev, int L, void* stream);
  * and amplitude tile fit LDS (C <= 64, e.g. L = 336) and B >= 64 - one workgroup per row with x[b] resident in
  * LDS.  FTN_SEL_ROW=1 / 0 in the environment forces / forbids the second form. */
 /* xch (ABI 9; may be NULL): also publish psum to slot `rank` of every rank's exchange buffer (see FtnExchange). */
+/* scratch_dev (ABI 10; may be NULL): ftn_period_spectrum_scratch_bytes(B, L, C) bytes of device memory.  With it,
+ * 64 < C <= 128 (d_model 128) runs the quarter-folded DFT as (row, 32-channel tile) workgroups that park their
+ * amplitudes [B][F][C] there, and a second launch takes the channel medians; without it (or when the function
+ * returns 0) those shapes run the (row, 32-bin block) kernel. */
+size_t ftn_period_spectrum_scratch_bytes(int B, int L, int C);
 int ftn_period_spectrum(const float* x_dev, int B, int L, int C, const void* table_dev,
-                        float* med_dev, double* psum_dev, void* stream, const FtnExchange* xch);
+                        float* med_dev, double* psum_dev, void* stream, const FtnExchange* xch, void* scratch_dev);
 /* S3-S5 (:119-157, PeriodGrouper.group :513-557, softmax/scatter :992-1009).
  * psum: [nparts][F] partial batch sums (summed in index order; nparts>1 is the
  * multi-GPU exchange of SURVEY §8e), Btotal = global batch.  Writes the

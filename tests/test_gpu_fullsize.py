@@ -328,7 +328,9 @@ def test_fused_stage_a_rejects_a_foreign_input(ftn, dev):
 
 # ---- row-resident selector kernels (k_spectrum_row, k_spectrum_rowq) -----------------------------------------
 @pytest.mark.parametrize("B,L,C", [(256, 336, 64), (70, 96, 64), (65, 97, 24), (64, 48, 7), (128, 3, 32), (64, 255, 33),
-                                   (64, 128, 40), (64, 8, 5)])
+                                   (64, 128, 40), (64, 8, 5),
+                                   # d_model > 64: the channel-tiled k_spectrum_rowq + k_median_rows (mode 2 / unset)
+                                   (64, 720, 128), (8, 96, 100), (3, 16, 130), (5, 336, 256), (4, 8, 65)])
 def test_row_resident_spectrum_forms_agree(B, L, C, dev, tmp_path):
     """ftn_period_spectrum has three kernels: k_spectrum (one workgroup per (row, 32-bin block)), k_spectrum_row
     (one workgroup per batch row, x[b] folded once into LDS; same MFMA sequence on the same operands: bit-identical)

@@ -237,10 +237,10 @@ def test_c_abi_rejects_bad_arguments_before_any_launch(ftn):
     xch = ftn.lib.FtnExchange()
     xch.world, xch.rank, xch.F_cap, xch.seq = 2, 0, 64, 0
     xch.slots[0] = fake
-    rc = lib.ftn_period_spectrum(fake, B, L, 16, fake, fake, fake, None, C.byref(xch))
+    rc = lib.ftn_period_spectrum(fake, B, L, 16, fake, fake, fake, None, C.byref(xch), None)
     assert rc < 0 and b"exchange" in lib.ftn_last_error()
     xch.seq = 1
-    rc = lib.ftn_period_spectrum(fake, B, L, 16, fake, fake, fake, None, C.byref(xch))
+    rc = lib.ftn_period_spectrum(fake, B, L, 16, fake, fake, fake, None, C.byref(xch), None)
     assert rc < 0 and b"not mapped" in lib.ftn_last_error()
     assert lib.ftn_exchange_bytes(2, 64) > 0 and lib.ftn_exchange_bytes(99, 64) == 0
 
