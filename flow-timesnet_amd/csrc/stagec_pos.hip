@@ -20,7 +20,10 @@ __device__ __forceinline__ void wait_vm_keep(int n) {
   }
 }
 
-template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF>
+// PF: every weight fragment is requested from LDS one fragment ahead of its use (two fragment buffers) and the res2
+// accumulators wait in a wave-private LDS slab between chunks, which is where the second buffer's registers come from.
+// Without it hipcc, at 254 registers, emits read -> wait -> 3 MFMAs per fragment: 43 exposed LDS round trips per chunk.
+template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF, bool PF>
 __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
   const MlpBfArgs& a = pa.c;
   constexpr int NL1 = 2 * SKM + 2 * SCP, NFR = NL1 + NOA + NOR;
@@ -98,8 +101,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
     for (int pz = 0; pz < NS; ++pz) *(bf8*)(xl + (size_t)(s * NS + pz) * 1024) = xp[pz];
   }
   f4 racc[NOR];
+  // (PF: the accumulators live in this wave's LDS slab, [NOR][64 lanes] f4, between their once-per-chunk updates)
+  char* __restrict__ rl = wlb + (size_t)NBUF * bufsz + (size_t)NWV * (SCP * NS * 1024) + (size_t)wave * (NOR * 1024) + lane * 16;
 #pragma unroll
-  for (int o = 0; o < NOR; ++o) racc[o] = *(const f4*)(a.bc + 16 * (NOA + o) + 4 * qa) * wsum;
+  for (int o = 0; o < NOR; ++o) {
+    racc[o] = *(const f4*)(a.bc + 16 * (NOA + o) + 4 * qa) * wsum;
+    if constexpr (PF) *(f4*)(rl + o * 1024) = racc[o];
+  }
 
   for (int it = 0; it < iters; ++it) {
     // ---- the groups of this pass: flat pixel index n = base[i] + tc (base wave-uniform)
@@ -202,6 +210,75 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)                                 // (needed after the res1 products, which cover the load)
         bo_t[t] = (hc * 2 + t) * 16 < a.FP ? *(const f4*)(a.bo + 16 * (hc * 2 + t) + 4 * qa) : f4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (PF) {
+        if (gcnt > 0) {
+          constexpr int NFG = 2 * SKM + NOA;                      // fragments one group walks: layer 1, then layer 2a
+          bf8 fr[2][NWP];
+          // res1(x) + b, once for all groups of the pass
+          {
+            bf8 xp[SCP][NS];
+            ldfrag(2 * SKM, fr[0]);
+#pragma unroll
+            for (int s = 0; s < SCP; ++s)
+#pragma unroll
+              for (int pz = 0; pz < NS; ++pz) xp[s][pz] = *(const bf8*)(xl + (size_t)(s * NS + pz) * 1024);
+#pragma unroll
+            for (int k = 0; k < 2 * SCP; ++k) {
+              if (k + 1 < 2 * SCP) ldfrag(2 * SKM + k + 1, fr[(k + 1) & 1]);
+              else ldfrag(0, fr[(k + 1) & 1]);                    // the first group's first fragment
+              __builtin_amdgcn_sched_barrier(0);
+              res1[k / SCP] = chain_bf<NS>(fr[k & 1], xp[k % SCP], res1[k / SCP]);
+            }
+          }
+          static_assert((2 * SCP) % 2 == 0, "group 0 starts on fragment buffer 0");
+          if (NS == 2) { res1[0] = res1[0] * a.inv_r; res1[1] = res1[1] * a.inv_r; }
+          f4 sacc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int i = 0; i < GB; ++i) {
+            if (i < gcnt) {
+              asm volatile("" : "+v"(wl_off));
+              f4 h[2] = {bo_t[0], bo_t[1]};
+              bf8 hp[NS];
+#pragma unroll
+              for (int k = 0; k < NFG; ++k) {
+                constexpr int dummy = 0; (void)dummy;
+                const int cur = (i * NFG + k) & 1;
+                // the next fragment of this group, or - behind the last one - the first fragment of the next group (the
+                // same weights for every group; after the pass's last group the read is simply not used)
+                ldfrag(k + 1 < 2 * SKM ? k + 1 : (k + 1 < NFG ? NL1 + (k + 1 - 2 * SKM) : 0), fr[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k < 2 * SKM) h[k / SKM] = chain_bf<NS>(fr[cur], mp[i][k % SKM], h[k / SKM]);
+                else aacc[i][k - 2 * SKM] = chain_bf<NS>(fr[cur], hp, aacc[i][k - 2 * SKM]);
+                if (k == 2 * SKM - 1) {
+                  // g_g = act(act(W_out1 m_g + b) + res1(x))  (:652-654, then TimesBlock's mid activation :757)
+#pragma unroll
+                  for (int t = 0; t < 2; ++t) {
+                    h[t] = act4<ACT>(NS == 2 ? h[t] * a.inv_o : h[t]) + res1[t];
+                    h[t] = act4<ACT>(h[t]);
+                    sacc[t] += h[t] * wg[i];
+                  }
+                  const float hv[8] = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+                  split_pieces<NS>(hv, hp);
+                }
+              }
+            }
+          }
+          if (!tail_blk) {
+            bf8 sp[NS], f2[2][NWP];
+            ldfrag(NL1 + NOA, f2[0]);
+            const float sv[8] = {sacc[0][0], sacc[0][1], sacc[0][2], sacc[0][3], sacc[1][0], sacc[1][1], sacc[1][2], sacc[1][3]};
+            split_pieces<NS>(sv, sp);
+#pragma unroll
+            for (int o = 0; o < NOR; ++o) {
+              if (o + 1 < NOR) ldfrag(NL1 + NOA + o + 1, f2[(o + 1) & 1]);
+              f4 r = *(const f4*)(rl + o * 1024);
+              __builtin_amdgcn_sched_barrier(0);
+              r = chain_bf<NS>(f2[o & 1], sp, r);
+              *(f4*)(rl + o * 1024) = r;
+            }
+          }
+        }
+      } else
       if (gcnt > 0) {
         // res1(x) + b, once for all groups of the pass (NS == 2: the accumulator carries sc_res1)
 #pragma unroll
@@ -287,18 +364,22 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
   if (!ok_m) return;
   float* __restrict__ rrow = pa.outRs + ((size_t)bm * L + tcm) * a.CP + 4 * qa;
 #pragma unroll
-  for (int o = 0; o < NOR; ++o) *(f4*)(rrow + 16 * o) = NS == 2 ? racc[o] * a.inv_r2 : racc[o];
+  for (int o = 0; o < NOR; ++o) {
+    if constexpr (PF) racc[o] = *(const f4*)(rl + o * 1024);
+    *(f4*)(rrow + 16 * o) = NS == 2 ? racc[o] * a.inv_r2 : racc[o];
+  }
 }
 
 static const int g_mlp_pos = [] { const char* e = getenv("FTN_MLP_POS"); return e ? atoi(e) : 1; }();      // 0: pixel-major k_mlp_bf_u1
 static const int g_mlp_pos_nwv = [] { const char* e = getenv("FTN_MLP_POS_NWV"); return e ? atoi(e) : 0; }();   // experiment: waves per workgroup
 static const int g_mlp_pos_abl = [] { const char* e = getenv("FTN_MLP_POS_ABL"); return e ? atoi(e) : 0; }();   // timing ablations
+static const int g_mlp_pos_pf = [] { const char* e = getenv("FTN_MLP_POS_PF"); return e ? atoi(e) : 1; }();     // 0: no fragment prefetch
 static const int g_mlp_pos_gb = [] { const char* e = getenv("FTN_MLP_POS_GB"); return e ? atoi(e) : 0; }();     // experiment: groups per pass
 
-template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF>
+template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF, bool PF>
 static int launch_mlp_pos_t(MlpPosArgs pa, int tail_units_bound, hipStream_t st) {
   constexpr int NFR = 2 * SKM + 2 * SCP + NOA + NOR;
-  const size_t lds = (size_t)NBUF * NFR * 3 * 1024 + (size_t)NWV * SCP * NS * 1024;
+  const size_t lds = (size_t)NBUF * NFR * 3 * 1024 + (size_t)NWV * SCP * NS * 1024 + (PF ? (size_t)NWV * NOR * 1024 : 0);
   if (lds > 160 * 1024) { ftn_set_error("position-major stage C needs %zu B of LDS", lds); return -1; }
   const long long units = (long long)pa.c.B * ((pa.c.L + 15) / 16);
   pa.n_main = (int)((units + NWV - 1) / NWV);
@@ -306,7 +387,7 @@ static int launch_mlp_pos_t(MlpPosArgs pa, int tail_units_bound, hipStream_t st)
   const int tail_wg = (tail_units_bound + NWV - 1) / NWV;
   pa.n_tail = tail_wg < 512 ? tail_wg : 512;
   pa.abl = g_mlp_pos_abl;
-  auto kfn = k_mlp_pos<ACT, XVEC, NS, SKM, SCP, NOA, NOR, NWV, GB, NBUF>;
+  auto kfn = k_mlp_pos<ACT, XVEC, NS, SKM, SCP, NOA, NOR, NWV, GB, NBUF, PF>;
   hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_mlp_pos): %s", hipGetErrorString(e)); return (int)e; }
   hipLaunchKernelGGL(kfn, dim3(pa.n_main + pa.n_tail), dim3(NWV * 64), lds, st, pa);
@@ -326,14 +407,17 @@ static int launch_mlp_pos64(const MlpPosArgs& pa, bool xvec, int tail_units_boun
   // groups per pass = what 256 registers hold: 5 with two activation pieces (f16x2) or one (bf16), 4 with three (bf16x3)
   constexpr int GBD = NS == 3 ? 4 : 5;
   const int gb = g_mlp_pos_gb ? g_mlp_pos_gb : GBD;
-#define FTN_POS_CASE(W, GBV, NB)                                                                                              \
-  if (nwv == W && gb == GBV)                                                                                                  \
-    return xvec ? launch_mlp_pos_t<ACT, true, NS, 2, 2, 3, 4, W, GBV, NB>(pa, tail_units_bound, st)                          \
-                : launch_mlp_pos_t<ACT, false, NS, 2, 2, 3, 4, W, GBV, NB>(pa, tail_units_bound, st);
-  FTN_POS_CASE(4, GBD, 1)
+#define FTN_POS_CASE(W, GBV, NB, PFV)                                                                                         \
+  if (nwv == W && gb == GBV && pf == PFV)                                                                                     \
+    return xvec ? launch_mlp_pos_t<ACT, true, NS, 2, 2, 3, 4, W, GBV, NB, PFV != 0>(pa, tail_units_bound, st)                \
+                : launch_mlp_pos_t<ACT, false, NS, 2, 2, 3, 4, W, GBV, NB, PFV != 0>(pa, tail_units_bound, st);
+  // fragment prefetch (template PF): the f16x2 default; FTN_MLP_POS_PF=0 the form without it
+  const int pf = (NS == 2 && nwv == 4 && gb == GBD) ? (g_mlp_pos_pf ? 1 : 0) : 0;
+  if constexpr (NS == 2) { FTN_POS_CASE(4, GBD, 1, 1) }
+  FTN_POS_CASE(4, GBD, 1, 0)
   if constexpr (NS == 2) {
-    FTN_POS_CASE(8, GBD, 2)
-    FTN_POS_CASE(4, 4, 1)
+    FTN_POS_CASE(8, GBD, 2, 0)
+    FTN_POS_CASE(4, 4, 1, 0)
   }
 #undef FTN_POS_CASE
   ftn_set_error("position-major stage C: no build for FTN_MLP_POS_NWV=%d FTN_MLP_POS_GB=%d", nwv, gb);

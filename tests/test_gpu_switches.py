@@ -17,7 +17,7 @@ SLICE = ("test_block_matches_reference and (b_c1_pipe-f16x2 or b_c2_pipe_k5-f16x
 @pytest.mark.parametrize("switch", ["FTN_MLP_SPLIT=0", "FTN_R_KEEPS_X=0", "FTN_FUSE_STAGE_A=0", "FTN_CONV_QUANT=0",
                                     "FTN_MLP_U1=0", "FTN_MLP_W16=1", "FTN_MLP_W4=1", "FTN_MLP_PFD=2",
                                     "FTN_CONV_GENERIC=1", "FTN_SEL_ROW=0", "FTN_SEL_ROW=1", "FTN_SEL_FLAT=1",
-                                    "FTN_MLP_POS=0", "FTN_MLP_POS_NWV=8", "FTN_MLP_POS_GB=4", "FTN_OUT_H=0"])
+                                    "FTN_MLP_POS=0", "FTN_MLP_POS_NWV=8", "FTN_MLP_POS_GB=4", "FTN_OUT_H=0", "FTN_MLP_POS_PF=0"])
 def test_parity_slice_under_switch(switch):
     name, value = switch.split("=")
     env = dict(os.environ, **{name: value})
