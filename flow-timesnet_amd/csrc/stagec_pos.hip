@@ -23,7 +23,7 @@ __device__ __forceinline__ void wait_vm_keep(int n) {
 // PF: every weight fragment is requested from LDS one fragment ahead of its use (two fragment buffers) and the res2
 // accumulators wait in a wave-private LDS slab between chunks, which is where the second buffer's registers come from.
 // Without it hipcc, at 254 registers, emits read -> wait -> 3 MFMAs per fragment: 43 exposed LDS round trips per chunk.
-template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF, bool PF>
+template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF, int PF>
 __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
   const MlpBfArgs& a = pa.c;
   constexpr int NL1 = 2 * SKM + 2 * SCP, NFR = NL1 + NOA + NOR;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
 #pragma unroll
   for (int o = 0; o < NOR; ++o) {
     racc[o] = *(const f4*)(a.bc + 16 * (NOA + o) + 4 * qa) * wsum;
-    if constexpr (PF) *(f4*)(rl + o * 1024) = racc[o];
+    if constexpr (PF == 1) *(f4*)(rl + o * 1024) = racc[o];
   }
 
   for (int it = 0; it < iters; ++it) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)                                 // (needed after the res1 products, which cover the load)
         bo_t[t] = (hc * 2 + t) * 16 < a.FP ? *(const f4*)(a.bo + 16 * (hc * 2 + t) + 4 * qa) : f4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (PF) {
+      if constexpr (PF == 1) {
         if (gcnt > 0) {
           constexpr int NFG = 2 * SKM + NOA;                      // fragments one group walks: layer 1, then layer 2a
           bf8 fr[2][NWP];
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
   float* __restrict__ rrow = pa.outRs + ((size_t)bm * L + tcm) * a.CP + 4 * qa;
 #pragma unroll
   for (int o = 0; o < NOR; ++o) {
-    if constexpr (PF) racc[o] = *(const f4*)(rl + o * 1024);
+    if constexpr (PF == 1) racc[o] = *(const f4*)(rl + o * 1024);
     *(f4*)(rrow + 16 * o) = NS == 2 ? racc[o] * a.inv_r2 : racc[o];
   }
 }
@@ -376,10 +376,10 @@ static const int g_mlp_pos_abl = [] { const char* e = getenv("FTN_MLP_POS_ABL");
 static const int g_mlp_pos_pf = [] { const char* e = getenv("FTN_MLP_POS_PF"); return e ? atoi(e) : 1; }();     // 0: no fragment prefetch
 static const int g_mlp_pos_gb = [] { const char* e = getenv("FTN_MLP_POS_GB"); return e ? atoi(e) : 0; }();     // experiment: groups per pass
 
-template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF, bool PF>
+template <int ACT, bool XVEC, int NS, int SKM, int SCP, int NOA, int NOR, int NWV, int GB, int NBUF, int PF>
 static int launch_mlp_pos_t(MlpPosArgs pa, int tail_units_bound, hipStream_t st) {
   constexpr int NFR = 2 * SKM + 2 * SCP + NOA + NOR;
-  const size_t lds = (size_t)NBUF * NFR * 3 * 1024 + (size_t)NWV * SCP * NS * 1024 + (PF ? (size_t)NWV * NOR * 1024 : 0);
+  const size_t lds = (size_t)NBUF * NFR * 3 * 1024 + (size_t)NWV * SCP * NS * 1024 + (PF == 1 ? (size_t)NWV * NOR * 1024 : 0);
   if (lds > 160 * 1024) { ftn_set_error("position-major stage C needs %zu B of LDS", lds); return -1; }
   const long long units = (long long)pa.c.B * ((pa.c.L + 15) / 16);
   pa.n_main = (int)((units + NWV - 1) / NWV);
@@ -409,8 +409,8 @@ static int launch_mlp_pos64(const MlpPosArgs& pa, bool xvec, int tail_units_boun
   const int gb = g_mlp_pos_gb ? g_mlp_pos_gb : GBD;
 #define FTN_POS_CASE(W, GBV, NB, PFV)                                                                                         \
   if (nwv == W && gb == GBV && pf == PFV)                                                                                     \
-    return xvec ? launch_mlp_pos_t<ACT, true, NS, 2, 2, 3, 4, W, GBV, NB, PFV != 0>(pa, tail_units_bound, st)                \
-                : launch_mlp_pos_t<ACT, false, NS, 2, 2, 3, 4, W, GBV, NB, PFV != 0>(pa, tail_units_bound, st);
+    return xvec ? launch_mlp_pos_t<ACT, true, NS, 2, 2, 3, 4, W, GBV, NB, PFV>(pa, tail_units_bound, st)                     \
+                : launch_mlp_pos_t<ACT, false, NS, 2, 2, 3, 4, W, GBV, NB, PFV>(pa, tail_units_bound, st);
   // fragment prefetch (template PF): the f16x2 default; FTN_MLP_POS_PF=0 the form without it
   const int pf = (NS == 2 && nwv == 4 && gb == GBD) ? (g_mlp_pos_pf ? 1 : 0) : 0;
   if constexpr (NS == 2) { FTN_POS_CASE(4, GBD, 1, 1) }
