@@ -419,7 +419,10 @@ def test_heads_match_oracle(B, S, D, N, hist, late, floor, ftn, dev):
     fv = torch.rand(N, generator=g) if floor == "vector" else None
     tail = x[:, -hist:, :]
     tail_full = tail if hist == S else torch.cat([tail, tail[:, -1:, :].expand(-1, S - hist, -1)], dim=1)
-    want_r, want_d = orc.model_heads(hidden, w_mu, b_mu, w_sg, b_sg, tail_full, lt,
+    # the oracle's dot products in fp64: with hidden[0, 0] x 30 the sum of |terms| reaches ~1e3, where an fp32 F.linear's
+    # own rounding (1e-7 of that) is as large as the tolerance below; the kernel's bf16x3 products carry ~1e-8 of it
+    dd = lambda t: None if t is None else t.double()
+    want_r, want_d = orc.model_heads(dd(hidden), dd(w_mu), dd(b_mu), dd(w_sg), dd(b_sg), dd(tail_full), dd(lt),
                                      fv.view(1, 1, N) if fv is not None else 1e-3)
     to = lambda t: None if t is None else t.to(dev)
     xd = x.to(dev)
