@@ -2800,7 +2800,8 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     ca.in = buf0; ca.bt_L = 0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
     // stage E on the 16-bit pipe (k_out_h): the second conv then leaves m' as activation pieces
-    const bool out_h = mlp_bf && ftn_out_h_enabled() != 0 && pl->w_out2fb != 0 && nsplit >= 2 && act_dtype == 0 && CA <= 64 && CP <= 64;
+    const bool out_h = (mlp_bf || mlp_bf128) && ftn_out_h_enabled() != 0 && pl->w_out2fb != 0 && nsplit >= 2 && act_dtype == 0 &&
+                       ((CA <= 64 && CP <= 64) || (CA <= 96 && CP <= 128));
     if (use_bf) {
       cb.in = (const __bf16*)buf0; cb.bt_L = 0; cb.bias = wb + (h2 ? pl->b_conv2s : pl->b_conv2); cb.out_p3 = out_h ? 1 : 0;
       for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf2[k]); cb.inv[k] = h2 ? 1.0f / pl->sc_conv2[k] : 1.0f; }
@@ -2815,7 +2816,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     oa.r_summed = mlp_pos ? 1 : 0;
     oa.range_flag = range_flag;
     const bool fast = CA <= 48 && CP <= 64;
-    if (fast) { oa.ln_g = ln_g; oa.ln_b = ln_b; oa.ln_eps = ln_eps; ln_g = nullptr; }   // fused epilogue
+    if (fast || out_h) { oa.ln_g = ln_g; oa.ln_b = ln_b; oa.ln_eps = ln_eps; ln_g = nullptr; }   // fused epilogue
     // FAST path: 16 pixels per wave (3 waves/SIMD; with 32 the kernel needs > 256 registers -> 1 wave/SIMD)
     const unsigned nblk_fast = (unsigned)(((long long)B * L + 63) / 64);
     if (out_h) {
