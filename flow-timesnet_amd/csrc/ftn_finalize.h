@@ -31,6 +31,7 @@ struct FinalizeArgs {
   // multi-GPU exchange (FtnExchange): the nparts partial sums are peer-written slots; ready[p * ready_n + i] turns
   // ready_seq when block i of rank p's k_colsum has stored its columns.  psum rows are psum_stride doubles apart.
   const unsigned long long* ready; unsigned long long ready_seq; int ready_n, psum_stride; int* xerr;
+  unsigned long long* dbg;   // diagnostic s_memtime stamps of the finalize workgroup's phases (ftn_debug_stamps which & 8), 8 words
 };
 
 // exchange buffer of one rank: two halves (seq parity); per half [world][F_cap] doubles, then [world][FTN_XCHG_NBLK]
@@ -41,7 +42,10 @@ __host__ __device__ inline size_t ftn_xchg_half_bytes(int world, int F_cap) {
 }
 __host__ __device__ inline size_t ftn_xchg_flags_off(int world, int F_cap) { return (size_t)world * F_cap * 8; }
 
-// One 256-thread workgroup.  Dynamic LDS: F floats.
+// One 256-thread workgroup.  Dynamic LDS: F rounded up to a multiple of 16 floats (scores) + as many 64-bit keys
+// (ftn_finalize_lds_bytes).
+static inline size_t ftn_finalize_lds_bytes(int F) { return (size_t)((F + 15) & ~15) * (sizeof(float) + sizeof(unsigned long long)); }
+
 __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
   const double* __restrict__ psum = fa.psum;
   const int nparts = fa.nparts, Btotal = fa.Btotal;
@@ -60,6 +64,8 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
   __shared__ float colmean[FTN_KMAX], gscore[FTN_KMAX];
   __shared__ int c_assign[FTN_KMAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto fstamp = [&](int slot) { if (fa.dbg != nullptr && tid == 0) fa.dbg[slot] = __builtin_amdgcn_s_memtime(); };
+  fstamp(0);
 
   const int pstride = fa.psum_stride > 0 ? fa.psum_stride : F;
   __shared__ int peers_late;
@@ -97,13 +103,52 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
     score[f] = (f == 0) ? -INFINITY : sc;
   }
   __syncthreads();
+  fstamp(1);
   int k = kcfg < F - 1 ? kcfg : F - 1;                            // :122-123
   if (k > FTN_KMAX) k = FTN_KMAX;
   if (k < 0) k = 0;
   // top-k by ONE wavefront, no barriers: every lane keeps the best of its strided share of the bins, a
   // shuffle butterfly reduces the 64 candidates, the winner's bin is retired (NaN) and the lane that owned it
   // rescans its share.  k <= 16 rounds of ~12 shuffles; ties resolve to the lowest bin index.
-  if (wave == 0) {
+  if (F <= 1024) {
+    // rank counting (round 3): every bin counts the bins that beat it (larger score, ties to the lower index - the
+    // order better() defines) with broadcast LDS reads; a bin of rank r < k is the r-th pick.  No dependent rounds:
+    // the k-round shuffle arg-max below was 16 k cycles of this workgroup's 44 k at F = 169, k = 5.  NaN scores never
+    // compare true, so they neither count nor are picked; missing picks stay -1.
+    // One 64-bit key per bin - the score mapped to an order-preserving integer in the high word, ~bin in the low word,
+    // 0 for NaN and for the padding - makes "beats" a single unsigned compare (mask-producing compare / select chains
+    // are slow here: the two-compare-and-index form of this loop took 27 k cycles).  Keys sit behind score[] in LDS.
+    const int FP16 = (F + 15) & ~15;
+    unsigned long long* __restrict__ key = (unsigned long long*)(score + FP16);
+    if (tid < FTN_KMAX) sel_idx[tid] = -1;
+    for (int f = tid; f < FP16; f += 256) {
+      unsigned long long kf = 0ull;
+      if (f < F) {
+        const float v = score[f];
+        const unsigned bits = __float_as_uint(v);
+        const unsigned mono = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);   // -inf .. +inf ascending, >= 0x007fffff
+        if (v == v) kf = ((unsigned long long)mono << 32) | (unsigned)(~f);
+      }
+      key[f] = kf;
+    }
+    __syncthreads();
+    for (int f = tid; f < F; f += 256) {
+      const unsigned long long kf = key[f];
+      if (kf != 0ull) {
+        int rank = 0;
+#pragma unroll 1
+        for (int g = 0; g < FP16; g += 16) {                      // eight reads in flight per LDS round trip
+          typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+          u2 a[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) a[c] = *(const u2*)(key + g + 2 * c);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) rank += (a[c].x > kf ? 1 : 0) + (a[c].y > kf ? 1 : 0);
+        }
+        if (rank < k) sel_idx[rank] = f;
+      }
+    }
+  } else if (wave == 0) {
     ArgMax mine = {0.f, -1};
     for (int f = lane; f < F; f += 64) {
       const float v = score[f];
@@ -130,6 +175,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
     }
   }
   __syncthreads();
+  fstamp(2);
   // periods, validity, grouping and tiling by the lanes of wave 0 in parallel - lane j owns candidate j, then
   // group j (FTN_KMAX <= 64).  Integer division has no hardware instruction here (~40 VALU ops each), and the
   // ~100 divisions of this section (period = ceil(L/idx), pad, cycles, the tile-geometry search) used to run one
@@ -176,17 +222,21 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
     // rank = number of distinct valid periods below mine
     bool first = valid;
     int rank = 0;
+    // (lane t's value for a compile-time t is a v_readlane_b32, not a ds_bpermute round trip: these three loops were
+    // ~100 dependent LDS-crossbar shuffles)
+    const unsigned long long validm = __ballot(valid);
+#pragma unroll
     for (int t = 0; t < FTN_KMAX; ++t) {
-      const int pt = __shfl(pc, t);
-      const bool vt = __shfl((int)valid, t) != 0;
-      if (vt && pt == pc && t < lane) first = false;
+      const int pt = __builtin_amdgcn_readlane(pc, t);
+      if (((validm >> t) & 1ull) && pt == pc && t < lane) first = false;
     }
+    const unsigned long long firstm = __ballot(first);
+#pragma unroll
     for (int t = 0; t < FTN_KMAX; ++t) {
-      const int pt = __shfl(pc, t);
-      const bool ft = __shfl((int)first, t) != 0;
-      if (ft && pt < pc) ++rank;
+      const int pt = __builtin_amdgcn_readlane(pc, t);
+      if (((firstm >> t) & 1ull) && pt < pc) ++rank;
     }
-    const int G = __popcll(__ballot(first));
+    const int G = __popcll(firstm);
     if (valid) sd.sel_group[lane] = rank;
     int tw = 0, th = 0, ntx = 0, nty = 0;
     if (first) ftn_tile_geometry(cyc, pc, &tw, &th, &ntx, &nty);
@@ -202,8 +252,9 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
     const int gpx = (lane < G) ? L + sd.g_pad[lane] : 0;
     const int gtl = (lane < G) ? sd.g_ntx[lane] * sd.g_nty[lane] : 0;
     int opx = 0, otl = 0;                                         // exclusive prefix of lanes < lane
+#pragma unroll
     for (int t = 0; t < FTN_KMAX; ++t) {
-      const int a_ = __shfl(gpx, t), b_ = __shfl(gtl, t);
+      const int a_ = __builtin_amdgcn_readlane(gpx, t), b_ = __builtin_amdgcn_readlane(gtl, t);
       if (t < lane) { opx += a_; otl += b_; }
     }
     if (lane <= FTN_KMAX) { sd.g_px_off[lane] = opx; sd.g_tile_off[lane] = otl; }   // lanes >= G hold the totals
@@ -213,6 +264,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
     if (lane == FTN_KMAX) { sd.total_px = opx; sd.tiles_per_row = otl; }
   }
   __syncthreads();
+  fstamp(3);
   // ---- TIMES_PERIOD_BINNING / TIMES_PERIOD_MAX_UNIQ (reference :350-437; resolved per block depth on the host and
   //      passed in): candidates are grouped by log bucket instead of by period, and / or only the `max_unique`
   //      groups with the largest batch-mean logsumexp survive, the others joining the kept group of nearest
@@ -389,6 +441,7 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
   // gathers are issued together (unrolled, they are one instruction each) and everything else is a rolled loop
   // over the nsel live candidates.
   const int nsel = sd.n_sel, G = sd.n_groups;
+  fstamp(4);
   for (int b = tid; b < B; b += 256) {
     const float* __restrict__ row = med + (size_t)b * F;
     float* __restrict__ ar = red[tid];
@@ -418,4 +471,5 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
 #pragma unroll 1
     for (int g = 0; g < FTN_KMAX; ++g) wts[(size_t)b * FTN_KMAX + g] = (g < G) ? wr[g] : 0.f;
   }
+  fstamp(5);
 }

@@ -2965,7 +2965,7 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
   if (min_period_threshold < 1) min_period_threshold = 1;
   if (min_period_threshold > pmax) min_period_threshold = pmax;
   const int F = L / 2 + 1;
-  const size_t lds = (size_t)F * sizeof(float);
+  const size_t lds = ftn_finalize_lds_bytes(F);
   FTN_CHECK_ARG(lds <= 48 * 1024, "ftn_period_finalize_stage_a: L=%d too long", L);
   const WsLayout wl = ws_layout(plan, B, L, max_groups, px_bound);
   const int CA = plan->nbr * plan->MP;
@@ -2977,6 +2977,7 @@ extern "C" int ftn_period_finalize_stage_a(const double* psum_dev, int nparts, i
   FinalizeArgs fa = {psum_dev, nparts, Btotal, med_dev, B, L, F, k_periods, pmax, min_period_threshold, desc_dev,
                      amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0 ? (float)log(log_base) : 0.f};
   if (xch != nullptr) ftn_xch_fill(xch, F, &fa);
+  fa.dbg = ((g_stamp_which & 8) && g_stamp_cap >= 8) ? g_stamp_buf : nullptr;
   PwArgs pa = {};
   pa.x = x_dev; pa.W = wblob_dev + plan->w_in1; pa.bias = wblob_dev + plan->b_in1; pa.out = (float*)((char*)ws_dev + wl.offA);
   pa.desc = nullptr; pa.B = B; pa.L = L; pa.C = plan->C; pa.KIN = plan->CP; pa.n_ot = CA / 16; pa.OUTC = CA;

@@ -985,7 +985,7 @@ extern "C" int ftn_period_finalize(const double* psum_dev, int nparts, int Btota
   if (min_period_threshold < 1) min_period_threshold = 1;
   if (min_period_threshold > pmax) min_period_threshold = pmax;
   const int F = L / 2 + 1;
-  const size_t lds = (size_t)F * sizeof(float);
+  const size_t lds = ftn_finalize_lds_bytes(F);
   FTN_CHECK_ARG(lds <= 48 * 1024, "ftn_period_finalize: L=%d too long", L);
   FinalizeArgs fa = {psum_dev, nparts, Btotal, med_dev, B, L, F, k_periods, pmax, min_period_threshold, desc_dev,
                      amps_dev, weights_dev, act_dtype, max_unique > 0 ? max_unique : 0, log_base > 1.0 ? (float)log(log_base) : 0.f};
