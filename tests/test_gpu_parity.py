@@ -82,6 +82,23 @@ def test_selector_matches_reference(name, manifest, golden, ftn, dev):
     np.testing.assert_allclose(psum.cpu().numpy() / case["B"], g["amp_mean"], rtol=RTOL, atol=2e-6 * scale)
 
 
+@pytest.mark.parametrize("L", [1024, 2100])
+def test_selector_top_k_both_forms(L, ftn, dev):
+    """The finalize workgroup picks its top-k by rank counting over 64-bit keys up to F = 1024 bins and by k rounds of
+    a single-wave shuffle arg-max beyond (ftn_finalize.h): L = 1024 (F = 513) and L = 2100 (F = 1051) against the
+    oracle, bit-exact indices, with planted periods so that the winners are not near-ties."""
+    from oracle import timesblock_oracle as orc
+
+    B, C, K = 4, 8, 5
+    x = torch.from_numpy(ftn.synth.make_input(B, L, C, seed=21, planted=(50, 21, 12, 7)))
+    want = orc.period_select(x, K, L)
+    sel = ftn.models.timesnet.FFTPeriodSelector(K, L)
+    with torch.inference_mode():
+        periods, _ = sel(x.to(dev))
+    assert sel.last_frequency_indices.tolist() == want.freq_idx
+    assert periods.tolist() == want.periods
+
+
 BLOCKS = ["b_tiny_min", "b_tiny_pipe", "b_c0_min", "b_c0_pipe", "b_c0_rect", "b_c0_wide1", "b_odd_min",
           "b_odd_pipe", "b_c1_min", "b_c1_pipe", "b_c2_pipe_k5", "b_noise_pipe"]
 
