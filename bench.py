@@ -287,7 +287,9 @@ def run_rank(args) -> None:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
-        events_every = 4 if args.steps >= 16 else 1
+        # six event records cost ~16 us of stream time per instrumented step: every 16th step of a long run (18 samples
+        # of every stage at the default K = 300), every 4th of a short one
+        events_every = 16 if args.steps >= 128 else (4 if args.steps >= 16 else 1)
         pkg.lib.check(lib.ftn_stage_timing(events_every), "ftn_stage_timing")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
