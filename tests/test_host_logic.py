@@ -428,3 +428,17 @@ def test_c_packer_matches_numpy_packer(C, d_ff, ratio, ks, act, engine, ftn):
         # pieces (what the kernels effectively multiply by) must agree
         assert np.mean(pc == pn) > 0.995
         np.testing.assert_allclose(pc, pn, rtol=1e-2, atol=1e-6)
+
+
+def test_pmc_latest_has_the_layout_bench_reads():
+    """bench.py takes roofline.traffic / roofline_conv / roofline_selector counter bytes from profiles/pmc_latest.json:
+    {"source", "workload", "kernels": {kernel name: {"avg_us", "hbm_bytes", ...}}}, matched by name prefix."""
+    import json
+    from pathlib import Path
+
+    d = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "pmc_latest.json").read_text())
+    assert {"source", "workload", "kernels"} <= set(d)
+    names = list(d["kernels"])
+    for prefix in ("k_mlp", "k_conv", "k_spectrum", "k_colsum", "k_finalize("):
+        hit = [n for n in names if (n + "(").startswith(prefix)]
+        assert hit and all(d["kernels"][n].get("hbm_bytes") is not None for n in hit), prefix
