@@ -1728,9 +1728,14 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   }
   {                                                            // every slab of the branch's one output tile, once
     const __bf16* __restrict__ src = a.W[br];
-    for (int f = wv; f < S * 3; f += 8)
+    // f16x2: piece 1 (A2 = A1 * 2^-11) is formed by the VALU in the slab loop and never read from LDS, so it is not
+    // fetched either
+    const int npc = NS == 2 ? S * 2 : S * 3;
+    for (int g = wv; g < npc; g += 8) {
+      const int f = NS == 2 ? (g >> 1) * 3 + (g & 1) * 2 : g;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 512 + lane * 8),
                                        (__attribute__((address_space(3))) void*)(wl + (size_t)f * 1024), 16, 0, 0);
+    }
   }
   const f4 bv = *(const f4*)(a.bias + br * a.out_stride_br + 4 * qa);
   const float inv = a.inv[br];
@@ -1838,13 +1843,18 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
       const int clo = max(0, hx - ci), chi = min(kw, p + hx - ci);
       const unsigned rm = (rhi > rlo) ? ((kmh >> (kh - rhi)) & (kmh << rlo)) & kmh : 0u;
       const unsigned cm = (chi > clo) ? ((kmw >> (kw - chi)) & (kmw << clo)) & kmw : 0u;
+      // bit s = tap 2s + h1 is inside the grid.  Row dy of the kernel (kw odd: its first tap has parity dy) holds the
+      // taps of this lane half at dx = par, par + 2, ... with par = (dy ^ h1) & 1, i.e. every other bit of the column
+      // mask, compressed, at slab (dy kw + par - h1) / 2: ~70 instructions per pixel unit instead of a 10-instruction
+      // step per slab (the 7x7 prologue spent 9 k of its 25 k cycles in that loop; tools/stamps.py)
+      const unsigned ce = (cm & 1u) | ((cm >> 1) & 2u) | ((cm >> 2) & 4u) | ((cm >> 3) & 8u);
+      const unsigned co = ((cm >> 1) & 1u) | ((cm >> 2) & 2u) | ((cm >> 3) & 4u) | ((cm >> 4) & 8u);
       unsigned m = 0u;
-      int dy = 0, dx = h1;                                     // tap h1 of slab 0 (kw >= 3 > h1)
-      for (int s2 = 0; s2 < S; ++s2) {
-        const unsigned ok = (dy < kh) ? ((rm >> dy) & (cm >> dx) & 1u) : 0u;
-        m |= ok << s2;
-        dx += 2;
-        if (dx >= kw) { dx -= kw; ++dy; }
+#pragma unroll
+      for (int dy = 0; dy < 7; ++dy) {                         // kh <= 7 here (fast path: 3x3 / 5x5 / 7x7)
+        const int par = (dy ^ h1) & 1;
+        const unsigned bits = par ? co : ce;
+        if (dy < kh && ((rm >> dy) & 1u)) m |= bits << ((dy * kw + par - h1) >> 1);
       }
       vmask[u] = pok[u] ? m : 0u;
     }
@@ -2497,7 +2507,8 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
   dim3 grid(grid_x, ftn_cdiv(B, ca.bpw), ca.nbr * ca.nchunk);
   if (gm.fast && ca.cin == 16 && ca.cout == 16) {
     // one workgroup per CU, shared out over the branches in proportion to their cost per batch row
-    // (~3.1 k cycles + 0.35 k per K-32 slab, fitted to tools/stamps.py); every branch gets at least one
+    // (~3.2 k cycles + 0.28 k per K-32 slab, beside a prologue worth ~17 k whatever the kernel size: fitted to
+    // tools/stamps.py after the closed-form tap masks, late round 3); every branch gets at least one
     static int ncu = 0;
     if (ncu == 0) {
       int dev = 0; hipDeviceProp_t prop;
@@ -2508,7 +2519,7 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
     size_t lds_fast = 0;
     for (int k = 0; k < ca.nbr; ++k) {
       const int S = (ca.kh[k] * ca.kw[k] + 1) / 2;
-      cost[k] = 3.1 + 0.345 * S; tot += cost[k];
+      cost[k] = 3.17 + 0.281 * S; tot += cost[k];
       const size_t need = (size_t)S * 3 * 1024 + 2 * (size_t)gm.region_bytes;
       if (need > lds_fast) lds_fast = need;
     }
@@ -2526,7 +2537,7 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
       bool found = false;
       for (int kk = 0; kk < ca.nbr; ++kk) {
         for (int r = 1; r <= rows_est; ++r) {
-          const double T = r * cost[kk];
+          const double T = r * cost[kk];                         // (the prologue is the same for every branch: it drops out)
           if (T >= bestT) break;
           int need[FTN_MAXBR], sum = 0;
           bool ok = true;
