@@ -110,8 +110,9 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& fa) {
   // top-k by ONE wavefront, no barriers: every lane keeps the best of its strided share of the bins, a
   // shuffle butterfly reduces the 64 candidates, the winner's bin is retired (NaN) and the lane that owned it
   // rescans its share.  k <= 16 rounds of ~12 shuffles; ties resolve to the lowest bin index.
-  if (F <= 1024) {
-    // rank counting (round 3): every bin counts the bins that beat it (larger score, ties to the lower index - the
+  if (F <= 256) {
+    // rank counting (round 3; one bin per thread - beyond 256 bins the F^2 / 256 compares per thread overtake the
+    // k rounds below): every bin counts the bins that beat it (larger score, ties to the lower index - the
     // order better() defines) with broadcast LDS reads; a bin of rank r < k is the r-th pick.  No dependent rounds:
     // the k-round shuffle arg-max below was 16 k cycles of this workgroup's 44 k at F = 169, k = 5.  NaN scores never
     // compare true, so they neither count nor are picked; missing picks stay -1.

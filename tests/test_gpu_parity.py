@@ -82,11 +82,11 @@ def test_selector_matches_reference(name, manifest, golden, ftn, dev):
     np.testing.assert_allclose(psum.cpu().numpy() / case["B"], g["amp_mean"], rtol=RTOL, atol=2e-6 * scale)
 
 
-@pytest.mark.parametrize("L", [1024, 2100])
+@pytest.mark.parametrize("L", [500, 1024, 2100])
 def test_selector_top_k_both_forms(L, ftn, dev):
-    """The finalize workgroup picks its top-k by rank counting over 64-bit keys up to F = 1024 bins and by k rounds of
-    a single-wave shuffle arg-max beyond (ftn_finalize.h): L = 1024 (F = 513) and L = 2100 (F = 1051) against the
-    oracle, bit-exact indices, with planted periods so that the winners are not near-ties."""
+    """The finalize workgroup picks its top-k by rank counting over 64-bit keys up to F = 256 bins and by k rounds of
+    a single-wave shuffle arg-max beyond (ftn_finalize.h): L = 500 (F = 251) against L = 1024 (F = 513) and L = 2100
+    (F = 1051), each against the oracle, bit-exact indices, with planted periods so that the winners are not near-ties."""
     from oracle import timesblock_oracle as orc
 
     B, C, K = 4, 8, 5
