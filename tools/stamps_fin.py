@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: phase timeline of the finalize workgroup inside k_finalize_pw (s_memtime stamps, ftn_debug_stamps
-which = 8).  Usage on the GPU box: python tools/stamps_fin.py"""
+which = 8).  Usage on the GPU box: python tools/stamps_fin.py [B L d_model]"""
 import sys
 from pathlib import Path
 
@@ -14,7 +14,8 @@ pkg = ge.load_package()
 lib = pkg.lib.load()
 T = pkg.models.timesnet
 dev = torch.device("cuda:0")
-B, L, C, K = 256, 336, 64, 5
+B, L, C = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 336, 64)
+K = 5
 ks = [(3, 3), (5, 5), (7, 7)]
 params = pkg.synth.make_inception_params(C, 4 * C, ks, 4.0, seed=0)
 blk = T.TimesBlock(C, ks, 0.0, "gelu", d_ff=4 * C, bottleneck_ratio=4.0)
