@@ -1348,7 +1348,8 @@ struct ConvBfArgs {
   int kh[FTN_MAXBR], kw[FTN_MAXBR], order[FTN_MAXBR];
   int bt_L;              // as ConvArgs.bt_L: > 0 = input rows per window position + one pad row
   float inv[FTN_MAXBR];  // f16x2: 2^-s of the branch's prescaled weights (applied to the accumulators)
-  int wg_off[FTN_MAXBR + 1];   // k_conv_bf_fast: workgroups [wg_off[k], wg_off[k+1]) serve branch k
+  int wg_off[2 * FTN_MAXBR + 1];   // k_conv_bf_fast: workgroups [wg_off[v], wg_off[v+1]) serve virtual branch v = branch * (cout / 16) + output tile
+  int nvb;               // virtual branches of the fast path: nbr * (cout / 16)
   int* range_flag;       // f16x2 piece output (out_p3): set when an output leaves the fp16 range; may be null
   int abl;               // timing ablations of k_conv_bf_fast (FTN_CONV_ABL; results wrong): 1 no output stores, 2 no region
                          // DMA after a tile's first row, 4 no barrier after a tile's first row, 8 no MFMA work
@@ -1608,11 +1609,15 @@ __global__ __launch_bounds__(512) void k_conv_bf(ConvBfArgs a) {
 #define CBF_FAST_ZBASE (FTN_REGION_PX * CBF_PX_BYTES)
 #define CBF_FAST_PLANE (CBF_FAST_ZBASE + 256)
 
+// fragment pieces a slab occupies in LDS: f16x2 keeps A1 and A3 only (A2 is formed by the VALU)
+template <int NS> struct CbfW { static constexpr int STR = NS == 2 ? 2 : 3; };
+
 template <int NS, int KH, int KW>
 __device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __restrict__ reg, const char* __restrict__ wlane,
                                                const int (&ld)[CBF_NU], const unsigned (&vmask)[CBF_NU],
                                                int RW32, bool half1) {
   constexpr int NWP = PxFmt<NS>::NW;
+  constexpr int WSTR = CbfW<NS>::STR;
   constexpr int NT = KH * KW, S = (NT + 1) / 2;
   bf8 bA[CBF_NU][NS], aA[NWP], bB[CBF_NU][NS], aB[NWP];
   auto load_slab = [&](int s, bf8 (&bp)[CBF_NU][NS], bf8 (&ap)[NWP]) {
@@ -1626,12 +1631,12 @@ __device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __r
       // A2 = A1 * 2^-11 exactly (an fp16 multiply by a power of two, subnormals included - the packer forms it the
       // same way), so it is not read: LDS reads and MFMA time are level in this kernel (9 : 9 per slab), the VALU
       // is not, and four v_pk_mul_f16 replace one ds_read_b128 of every slab
-      ap[0] = *(const bf8*)(wlane + (s * 3 + 0) * 1024);
-      ap[2] = *(const bf8*)(wlane + (s * 3 + 2) * 1024);
+      ap[0] = *(const bf8*)(wlane + (s * WSTR + 0) * 1024);
+      ap[2] = *(const bf8*)(wlane + (s * WSTR + 1) * 1024);
       ap[1] = __builtin_bit_cast(bf8, __builtin_bit_cast(h8, ap[0]) * (_Float16)0.00048828125f);
     } else {
 #pragma unroll
-      for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(wlane + (s * 3 + pz) * 1024);
+      for (int pz = 0; pz < NWP; ++pz) ap[pz] = *(const bf8*)(wlane + (s * WSTR + pz) * 1024);
     }
 #pragma unroll
     for (int u = 0; u < CBF_NU; ++u) {
@@ -1698,18 +1703,24 @@ __device__ __forceinline__ void conv_fast_row(f4 (&acc)[CBF_NU], const char* __r
 // are DMA'd once per workgroup instead of once per 8 rows, and every CU finishes at about the same time; the
 // (tile, 8-row chunk, branch) grid of k_conv_bf runs 480 unequal workgroups (49 / 25 / 9 taps) on 256 CUs in
 // roughly 1.4 rounds - 92 us for 66 us of work (tools/stamps.py).
-template <int NS>
+// NCI = 16-channel input groups per branch (mid 16: 1; mid 32: 2, late round 3).  With two, a workgroup is bound to a
+// (branch, output tile) pair - a "virtual branch" - keeps both input groups' fragment sets in LDS and walks the
+// (batch row, input group) sequence through the same two region buffers: the second group's products add into the
+// first's accumulators, the row's outputs are stored once.
+template <int NS, int NCI>
 __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   constexpr int PXE = PxFmt<NS>::ELEMS;
   constexpr int plane = CBF_FAST_PLANE;
+  constexpr int WSTR = CbfW<NS>::STR;
   const FtnDesc* __restrict__ d = a.desc;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 15, qa = lane >> 4;
   bool range_bad = false;                                       // f16x2: an output left the fp16 range
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  int br = 0;
-  while (br + 1 < a.nbr && (int)blockIdx.x >= a.wg_off[br + 1]) ++br;
-  const int wgi = (int)blockIdx.x - a.wg_off[br], nwg = a.wg_off[br + 1] - a.wg_off[br];
+  int vb = 0;
+  while (vb + 1 < a.nvb && (int)blockIdx.x >= a.wg_off[vb + 1]) ++vb;
+  const int wgi = (int)blockIdx.x - a.wg_off[vb], nwg = a.wg_off[vb + 1] - a.wg_off[vb];
+  const int nco = a.cout >> 4, br = vb / nco, cot = vb - br * nco;   // branch, output tile of the branch
   const int G = d->n_groups, tiles_total = d->tiles_per_row;
   const long long rows_total = (long long)tiles_total * a.B;
   const int row_lo = (int)(rows_total * wgi / nwg), row_hi = (int)(rows_total * (wgi + 1) / nwg);
@@ -1720,24 +1731,27 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
   const int S = (ntaps + 1) >> 1;
   if (a.dbg != nullptr && threadIdx.x == 0 && wgid * 8 + 7 < a.dbg_cap) { a.dbg[wgid * 8 + 6] = __builtin_amdgcn_s_memrealtime(); a.dbg[wgid * 8 + 4] = (unsigned long long)ntaps; a.dbg[wgid * 8 + 5] = ((unsigned long long)row_lo << 32) | (unsigned)row_hi; }
   char* __restrict__ wl = ldsb;
-  char* __restrict__ rbuf0 = ldsb + (size_t)S * 3 * 1024;      // behind THIS branch's weight fragments
+  char* __restrict__ rbuf0 = ldsb + (size_t)NCI * S * WSTR * 1024;   // behind THIS (branch, tile)'s weight fragments
   static_assert(CBF_FAST_ZBASE % 256 == 0, "the zero block must start on a 256-byte boundary");
   if (threadIdx.x < 2 * NS * 16) {                           // zero blocks of both region buffers
     const int pl = threadIdx.x >> 4;
     *(f4*)(rbuf0 + (size_t)(pl / NS) * a.region_bytes + (size_t)(pl % NS) * plane + CBF_FAST_ZBASE + (threadIdx.x & 15) * 16) = f4{0.f, 0.f, 0.f, 0.f};
   }
   {                                                            // every slab of the branch's one output tile, once
-    const __bf16* __restrict__ src = a.W[br];
-    // f16x2: piece 1 (A2 = A1 * 2^-11) is formed by the VALU in the slab loop and never read from LDS, so it is not
-    // fetched either
-    const int npc = NS == 2 ? S * 2 : S * 3;
-    for (int g = wv; g < npc; g += 8) {
-      const int f = NS == 2 ? (g >> 1) * 3 + (g & 1) * 2 : g;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 512 + lane * 8),
-                                       (__attribute__((address_space(3))) void*)(wl + (size_t)f * 1024), 16, 0, 0);
+    // f16x2: piece 1 (A2 = A1 * 2^-11) is formed by the VALU in the slab loop, so it is neither fetched nor given
+    // room in LDS (packed layout: [cin group][cout tile][slab][3 pieces] x 1 KB; LDS: [cin group][slab][WSTR])
+    const int npc = S * WSTR;
+#pragma unroll
+    for (int gi = 0; gi < NCI; ++gi) {
+      const __bf16* __restrict__ src = a.W[br] + (size_t)(gi * nco + cot) * S * 3 * 512;
+      for (int g = wv; g < npc; g += 8) {
+        const int f = NS == 2 ? (g >> 1) * 3 + (g & 1) * 2 : g;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(wl + (size_t)(gi * npc + g) * 1024), 16, 0, 0);
+      }
     }
   }
-  const f4 bv = *(const f4*)(a.bias + br * a.out_stride_br + 4 * qa);
+  const f4 bv = *(const f4*)(a.bias + br * a.out_stride_br + 16 * cot + 4 * qa);
   const float inv = a.inv[br];
   const int in_groups = a.INC >> 4;
   const int btL = a.bt_L;
@@ -1797,13 +1811,13 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
     const __bf16* __restrict__ src_pad = in_br + (size_t)a.B * btL * in_groups * PXE;
     const size_t row_stride = (size_t)(btL > 0 ? btL : P) * in_groups * PXE;
     const __bf16* __restrict__ src0 = in_br + (btL > 0 ? (size_t)0 : img0 * in_groups * PXE);
-    auto dma_region = [&](int b, int buf) {
-      const __bf16* __restrict__ src = src0 + (size_t)b * row_stride;
+    auto dma_region = [&](int b, int gi, int buf) {           // input group gi of batch row b
+      const __bf16* __restrict__ src = src0 + (size_t)b * row_stride + gi * PXE;
       char* __restrict__ dstb = rbuf0 + (size_t)buf * a.region_bytes;
 #pragma unroll
       for (int k = 0; k < KPMAX; ++k) {
         if (wv + 8 * k < npc) {
-          const __bf16* __restrict__ rowp = ((ppad >> k) & 1u) ? src_pad : src;
+          const __bf16* __restrict__ rowp = ((ppad >> k) & 1u) ? src_pad + gi * PXE : src;
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp + poff[k]),
                                            (__attribute__((address_space(3))) void*)(dstb + pdst[k]), 16, 0, 0);
         }
@@ -1813,7 +1827,7 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
     // tile's readers must be done with the buffers first)
     if (!first_tile) __syncthreads();
     first_tile = false;
-    dma_region(b_begin, 0);
+    dma_region(b_begin, 0, 0);
     // per-lane pixel bookkeeping, once per tile.  Tap validity (conv zero padding at the grid border): bit s of
     // vmask[u] = tap 2s + h1 lies inside the grid for this lane's pixel, from a row mask and a column mask and a
     // division-free walk over the taps (a runtime tl / kw per slab and unit cost 20 k cycles of a 7x7 tile's
@@ -1834,7 +1848,7 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
       ld[u] = ((ri - R0 - hy) * RW + (ci - C0 - hx)) * CBF_PX_BYTES + (qa & 1) * 16;
       oidx[u] = ri * p + ci;
       {
-        const int ch = br * a.out_stride_br;
+        const int ch = br * a.out_stride_br + 16 * cot;
         ooff[u] = a.out_p3 ? (unsigned)((oidx[u] * (a.OUTC >> 4) + (ch >> 4)) * PXE)
                            : (unsigned)(oidx[u] * a.OUTC + ch + 4 * qa);
       }
@@ -1861,22 +1875,33 @@ __global__ __launch_bounds__(512) void k_conv_bf_fast(ConvBfArgs a) {
     int it = 0;
     int keep = 0;                                             // output stores issued behind the newest region DMA
     const int nst_row = a.dbg != nullptr ? 99 : nu * (a.out_p3 ? 2 : 1);
+    const char* __restrict__ wlane = wl + lane * 16;
     for (int b = b_begin; b < b_end; ++b) {
-      if (!((a.abl & 4) && b > b_begin)) barrier_keep_vm(keep);   // row b (and, the first time, the weights) have landed
-      keep = __builtin_amdgcn_readfirstlane(nst_row);
-      if (b == b_begin) stamp(a.dbg, a.dbg_cap, wgid, 1);
-      if (b == b_begin + 1) stamp(a.dbg, a.dbg_cap, wgid, 2);
-      if (b + 1 < b_end && !(a.abl & 2)) dma_region(b + 1, (it + 1) & 1);
       f4 acc[CBF_NU];
 #pragma unroll
       for (int u = 0; u < CBF_NU; ++u) acc[u] = bv;
-      const char* __restrict__ reg = rbuf0 + (size_t)((a.abl & 2) ? 0 : (it & 1)) * a.region_bytes;
-      ++it;
-      const char* __restrict__ wlane = wl + lane * 16;
-      if (a.abl & 8) {}
-      else if (kw == 7) conv_fast_row<NS, 7, 7>(acc, reg, wlane, ld, vmask, RW * CBF_PX_BYTES, h1 != 0);
-      else if (kw == 5) conv_fast_row<NS, 5, 5>(acc, reg, wlane, ld, vmask, RW * CBF_PX_BYTES, h1 != 0);
-      else conv_fast_row<NS, 3, 3>(acc, reg, wlane, ld, vmask, RW * CBF_PX_BYTES, h1 != 0);
+      // the (row, input group) items walk the two region buffers in turn; the item behind this one is requested now
+      // (rolled: one copy of the unrolled slab loops)
+#pragma unroll 1
+      for (int gi = 0; gi < NCI; ++gi) {
+        if (!((a.abl & 4) && (b > b_begin || gi > 0))) barrier_keep_vm(keep);   // this item (and, the first time, the weights) have landed
+        keep = gi == NCI - 1 ? __builtin_amdgcn_readfirstlane(nst_row) : 0;   // stores only follow a row's last group
+        if (gi == 0) {
+          if (b == b_begin) stamp(a.dbg, a.dbg_cap, wgid, 1);
+          if (b == b_begin + 1) stamp(a.dbg, a.dbg_cap, wgid, 2);
+        }
+        if (!(a.abl & 2)) {
+          if (gi + 1 < NCI) dma_region(b, gi + 1, (it + 1) & 1);
+          else if (b + 1 < b_end) dma_region(b + 1, 0, (it + 1) & 1);
+        }
+        const char* __restrict__ reg = rbuf0 + (size_t)((a.abl & 2) ? 0 : (it & 1)) * a.region_bytes;
+        ++it;
+        const char* __restrict__ wg_ = wlane + (size_t)gi * S * WSTR * 1024;
+        if (a.abl & 8) {}
+        else if (kw == 7) conv_fast_row<NS, 7, 7>(acc, reg, wg_, ld, vmask, RW * CBF_PX_BYTES, h1 != 0);
+        else if (kw == 5) conv_fast_row<NS, 5, 5>(acc, reg, wg_, ld, vmask, RW * CBF_PX_BYTES, h1 != 0);
+        else conv_fast_row<NS, 3, 3>(acc, reg, wg_, ld, vmask, RW * CBF_PX_BYTES, h1 != 0);
+      }
       // uniform row base + per-lane offsets fixed for the tile (ooff)
       const size_t nimg = img0 + (size_t)b * P;
       if ((a.abl & 1) && acc[0][0] != 12345.678f) {}
@@ -2418,7 +2443,9 @@ struct ConvBfGeom { int NCO; size_t lds; int plane_bytes, region_bytes, wbytes, 
 static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int cout, int npieces) {
   ConvBfGeom gm = {0, 0, 0, 0, 0, 0, false};
   int region_px = 1, smax = 1;
-  bool sq357 = cout == 16;                                              // k_conv_bf_fast: mid <= 16, kernels 3x3 / 5x5 / 7x7
+  // k_conv_bf_fast: mid <= 16 (one input group, one output tile per branch) or, f16x2 only, mid 17..32 (two and two),
+  // kernels 3x3 / 5x5 / 7x7
+  bool sq357 = cout == 16 || (cout == 32 && npieces == 2);
   for (int k = 0; k < nbr; ++k) {
     if (!(kh[k] == kw[k] && (kh[k] == 3 || kh[k] == 5 || kh[k] == 7))) sq357 = false;
     if (kh[k] > 31 || kw[k] > 31) return gm;
@@ -2431,11 +2458,15 @@ static ConvBfGeom conv_bf_geom(int L, int nbr, const int* kh, const int* kw, int
   gm.region_bytes = npieces * gm.plane_bytes;
   const int nco_tot = cout / 16;
   if (sq357 && region_px <= FTN_REGION_PX && !g_conv_generic) {
-    gm.fast = true; gm.NCO = 1; gm.sgroup = smax;
-    gm.plane_bytes = CBF_FAST_PLANE; gm.region_bytes = npieces * CBF_FAST_PLANE;
-    gm.wbytes = smax * 3 * 1024;
-    gm.lds = (size_t)gm.wbytes + 2 * (size_t)gm.region_bytes;
-    return gm;
+    const int nci = cout / 16, wstr = npieces == 2 ? 2 : 3;       // (the fast path is only taken for cin == cout)
+    const size_t need = (size_t)nci * smax * wstr * 1024 + 2 * (size_t)npieces * CBF_FAST_PLANE;
+    if (need <= 160 * 1024) {
+      gm.fast = true; gm.NCO = 1; gm.sgroup = smax;
+      gm.plane_bytes = CBF_FAST_PLANE; gm.region_bytes = npieces * CBF_FAST_PLANE;
+      gm.wbytes = nci * smax * wstr * 1024;
+      gm.lds = need;
+      return gm;
+    }
   }
   // Output tiles per workgroup: more tiles share every pixel fragment read.  When all slabs' weights do not fit
   // beside the two region buffers, they are staged in groups of `sgroup` slabs.
@@ -2469,17 +2500,20 @@ static int launch_conv_bf_n(const ConvBfArgs& ca, const ConvBfGeom& gm, dim3 gri
   return launch_conv_bf_t<1, NS>(ca, grid, gm.lds, st);
 }
 
-static int launch_conv_bf_fast(const ConvBfArgs& ca, const ConvBfGeom& gm, dim3 grid, int nsplit, hipStream_t st) {
-  hipError_t e = hipSuccess;
-  if (nsplit == 3) e = hipFuncSetAttribute((const void*)k_conv_bf_fast<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
-  else if (nsplit == 2) e = hipFuncSetAttribute((const void*)k_conv_bf_fast<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
-  else e = hipFuncSetAttribute((const void*)k_conv_bf_fast<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
+template <int NS, int NCI>
+static int launch_conv_bf_fast_t(const ConvBfArgs& ca, const ConvBfGeom& gm, dim3 grid, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute((const void*)k_conv_bf_fast<NS, NCI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gm.lds);
   if (e != hipSuccess) { ftn_set_error("hipFuncSetAttribute(k_conv_bf_fast): %s", hipGetErrorString(e)); return (int)e; }
-  if (nsplit == 3) hipLaunchKernelGGL(k_conv_bf_fast<3>, grid, dim3(512), gm.lds, st, ca);
-  else if (nsplit == 2) hipLaunchKernelGGL(k_conv_bf_fast<2>, grid, dim3(512), gm.lds, st, ca);
-  else hipLaunchKernelGGL(k_conv_bf_fast<1>, grid, dim3(512), gm.lds, st, ca);
+  hipLaunchKernelGGL((k_conv_bf_fast<NS, NCI>), grid, dim3(512), gm.lds, st, ca);
   FTN_CHECK_LAUNCH();
   return 0;
+}
+
+static int launch_conv_bf_fast(const ConvBfArgs& ca, const ConvBfGeom& gm, dim3 grid, int nsplit, hipStream_t st) {
+  if (ca.cin == 32) return launch_conv_bf_fast_t<2, 2>(ca, gm, grid, st);        // mid 32: f16x2 only (conv_bf_geom)
+  if (nsplit == 3) return launch_conv_bf_fast_t<3, 1>(ca, gm, grid, st);
+  if (nsplit == 2) return launch_conv_bf_fast_t<2, 1>(ca, gm, grid, st);
+  return launch_conv_bf_fast_t<1, 1>(ca, gm, grid, st);
 }
 
 static const bool g_conv_quant = [] { const char* e = getenv("FTN_CONV_QUANT"); return e == nullptr || e[0] != '0'; }();
@@ -2505,7 +2539,9 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
     ca.order[jj + 1] = v;
   }
   dim3 grid(grid_x, ftn_cdiv(B, ca.bpw), ca.nbr * ca.nchunk);
-  if (gm.fast && ca.cin == 16 && ca.cout == 16) {
+  if (gm.fast && ((ca.cin == 16 && ca.cout == 16) || (ca.cin == 32 && ca.cout == 32 && nsplit == 2))) {
+    // virtual branches: (branch, 16-channel output tile); with two input groups a batch row walks two slab loops
+    const int nci = ca.cin / 16, nco = ca.cout / 16, nvb = ca.nbr * nco, wstr = nsplit == 2 ? 2 : 3;
     // one workgroup per CU, shared out over the branches in proportion to their cost per batch row
     // (~3.2 k cycles + 0.28 k per K-32 slab, beside a prologue worth ~17 k whatever the kernel size: fitted to
     // tools/stamps.py after the closed-form tap masks, late round 3); every branch gets at least one
@@ -2513,62 +2549,63 @@ static int launch_conv_bf(ConvBfArgs& ca, const ConvBfGeom& gm, int B, int grid_
     if (ncu == 0) {
       int dev = 0; hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-      if (ncu < ca.nbr) ncu = 256;
+      if (ncu < 2 * FTN_MAXBR) ncu = 256;
     }
-    double cost[FTN_MAXBR], tot = 0.0;
+    double cost[2 * FTN_MAXBR], tot = 0.0;
     size_t lds_fast = 0;
-    for (int k = 0; k < ca.nbr; ++k) {
-      const int S = (ca.kh[k] * ca.kw[k] + 1) / 2;
-      cost[k] = 3.17 + 0.281 * S; tot += cost[k];
-      const size_t need = (size_t)S * 3 * 1024 + 2 * (size_t)gm.region_bytes;
+    for (int v = 0; v < nvb; ++v) {
+      const int k = v / nco, S = (ca.kh[k] * ca.kw[k] + 1) / 2;
+      cost[v] = 3.17 + 0.281 * S * nci; tot += cost[v];
+      const size_t need = (size_t)nci * S * wstr * 1024 + 2 * (size_t)gm.region_bytes;
       if (need > lds_fast) lds_fast = need;
     }
-    int used = 0, nwg[FTN_MAXBR];
-    for (int k = 0; k < ca.nbr; ++k) { nwg[k] = (int)(ncu * cost[k] / tot); if (nwg[k] < 1) nwg[k] = 1; used += nwg[k]; }
-    for (int k = 0; used < ncu; k = (k + 1) % ca.nbr) { ++nwg[k]; ++used; }     // leftovers round-robin from the first branch
-    for (int k = 0; used > ncu && k < ca.nbr; ++k) while (nwg[k] > 1 && used > ncu) { --nwg[k]; --used; }
+    int used = 0, nwg[2 * FTN_MAXBR];
+    for (int k = 0; k < nvb; ++k) { nwg[k] = (int)(ncu * cost[k] / tot); if (nwg[k] < 1) nwg[k] = 1; used += nwg[k]; }
+    for (int k = 0; used < ncu; k = (k + 1) % nvb) { ++nwg[k]; ++used; }     // leftovers round-robin from the first branch
+    for (int k = 0; used > ncu && k < nvb; ++k) while (nwg[k] > 1 && used > ncu) { --nwg[k]; --used; }
     // Rows are whole units: a 7x7 workgroup with 11 rows ends 9 % after one with 10 (tools/stamps.py: the launch
     // ended at 79 us with the median workgroup done at 66).  With an estimate of the row count (the descriptor is on
     // the device: groups bound x tiles of a typical grid x batch rows) pick the split that minimises
     // max_k ceil(rows / nwg_k) * cost_k; a wrong estimate only costs balance, the kernel derives the ranges itself.
     if (rows_est > 0 && g_conv_quant) {
       double bestT = 1e300;
-      int best[FTN_MAXBR];
+      int best[2 * FTN_MAXBR];
       bool found = false;
-      for (int kk = 0; kk < ca.nbr; ++kk) {
+      for (int kk = 0; kk < nvb; ++kk) {
         for (int r = 1; r <= rows_est; ++r) {
           const double T = r * cost[kk];                         // (the prologue is the same for every branch: it drops out)
           if (T >= bestT) break;
-          int need[FTN_MAXBR], sum = 0;
+          int need[2 * FTN_MAXBR], sum = 0;
           bool ok = true;
-          for (int k = 0; k < ca.nbr && ok; ++k) {
+          for (int k = 0; k < nvb && ok; ++k) {
             const int per = (int)(T / cost[k] + 1e-9);
             if (per < 1) { ok = false; break; }
             need[k] = (rows_est + per - 1) / per;
             sum += need[k];
           }
-          if (ok && sum <= ncu) { bestT = T; for (int k = 0; k < ca.nbr; ++k) best[k] = need[k]; found = true; break; }
+          if (ok && sum <= ncu) { bestT = T; for (int k = 0; k < nvb; ++k) best[k] = need[k]; found = true; break; }
         }
       }
       if (found) {
         int sum = 0;
-        for (int k = 0; k < ca.nbr; ++k) sum += best[k];
+        for (int k = 0; k < nvb; ++k) sum += best[k];
         // spare workgroups go where they shorten the longest branch next
         while (sum < ncu) {
           int arg = 0; double worst = -1.0;
-          for (int k = 0; k < ca.nbr; ++k) {
+          for (int k = 0; k < nvb; ++k) {
             const double t = (double)((rows_est + best[k] - 1) / best[k]) * cost[k];
             if (t > worst) { worst = t; arg = k; }
           }
           ++best[arg]; ++sum;
         }
-        for (int k = 0; k < ca.nbr; ++k) nwg[k] = best[k];
+        for (int k = 0; k < nvb; ++k) nwg[k] = best[k];
       }
     }
+    ca.nvb = nvb;
     ca.wg_off[0] = 0;
-    for (int k = 0; k < ca.nbr; ++k) ca.wg_off[k + 1] = ca.wg_off[k] + nwg[k];
+    for (int k = 0; k < nvb; ++k) ca.wg_off[k + 1] = ca.wg_off[k] + nwg[k];
     const ConvBfGeom gmf = {gm.NCO, lds_fast, gm.plane_bytes, gm.region_bytes, gm.wbytes, gm.sgroup, true};
-    return launch_conv_bf_fast(ca, gmf, dim3((unsigned)ca.wg_off[ca.nbr]), nsplit, st);
+    return launch_conv_bf_fast(ca, gmf, dim3((unsigned)ca.wg_off[nvb]), nsplit, st);
   }
   if (nsplit == 3) return launch_conv_bf_n<3>(ca, gm, grid, st);
   if (nsplit == 2) return launch_conv_bf_n<2>(ca, gm, grid, st);
