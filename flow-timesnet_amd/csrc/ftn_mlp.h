@@ -107,4 +107,6 @@ struct MlpPosArgs {
 
 // position-major stage C of the d_model-64 shape (stagec_pos.hip); act 0 GELU / 1 ReLU, nsplit = activation pieces
 int ftn_launch_mlp_pos64(const MlpPosArgs& pa, int act, int nsplit, bool xvec, int tail_units_bound, hipStream_t st);
+// the same for the d_model-128 shape (f16x2 only)
+int ftn_launch_mlp_pos128(const MlpPosArgs& pa, int act, bool xvec, int tail_units_bound, hipStream_t st);
 int ftn_mlp_pos_enabled();

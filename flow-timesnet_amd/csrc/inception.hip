@@ -2745,9 +2745,16 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // (OutArgs.r_keeps_x); every other combination subtracts x in stage C as the reference's delta does
     const bool r_keeps_x = mlp_bf && g_mlp_u1 && g_r_keeps_x && act_dtype == 0 && (CA + 31) / 32 == 2 && (CP + 31) / 32 == 2 &&
                            n_ot_c == 7 && CA <= 48 && CP <= 64;
+    // stage E on the 16-bit pipe (k_out_h): the second conv then leaves m' as activation pieces
+    const bool out_h = (mlp_bf || mlp_bf128) && ftn_out_h_enabled() != 0 && pl->w_out2fb != 0 && nsplit >= 2 && act_dtype == 0 &&
+                       ((CA <= 64 && CP <= 64) || (CA <= 96 && CP <= 128));
     // position-major stage C (k_mlp_pos) for the same shape: res1 / res2 once per window position, R group-summed
-    const bool mlp_pos = mlp_bf && g_mlp_u1 && ftn_mlp_pos_enabled() != 0 && act_dtype == 0 && (CA + 31) / 32 == 2 && (CP + 31) / 32 == 2 &&
-                         n_ot_c == 7 && CA == 48 && CP == 64;
+    const bool mlp_pos64 = mlp_bf && g_mlp_u1 && ftn_mlp_pos_enabled() != 0 && act_dtype == 0 && (CA + 31) / 32 == 2 && (CP + 31) / 32 == 2 &&
+                           n_ot_c == 7 && CA == 48 && CP == 64;
+    // the d_model-128 shape (f16x2): two groups per pass, one 8-wave workgroup per CU (stagec_pos.hip)
+    // (its group-summed R is only understood by k_out_h at this width)
+    const bool mlp_pos128 = mlp_bf128 && out_h && g_mlp_u1 && ftn_mlp_pos_enabled() != 0 && act_dtype == 0 && nsplit == 2;
+    const bool mlp_pos = mlp_pos64 || mlp_pos128;
     if (use_bf) {
       cb.range_flag = range_flag;
       cb.in = (const __bf16*)bufA; cb.bt_L = L; cb.out = buf1; cb.out_p3 = (mlp_bf || mlp_bf128) ? 1 : 0; cb.bias = wb + (h2 ? pl->b_conv1s : pl->b_conv1); cb.desc = desc;
@@ -2821,7 +2828,7 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
       mb.nsKM = (CA + 31) / 32; mb.nsCP = (CP + 31) / 32;
       mb.n_oa = CA / 16; mb.n_ot = n_ot_c; mb.n_hchunks = pl->n_hchunks; mb.per_chunk = pl->cfragbf_per_chunk;
       if (mb.per_chunk != 2 * mb.nsKM + 2 * mb.nsCP + mb.n_ot) { ftn_set_error("plan/cfragbf layout mismatch"); return -1; }
-      if (mlp_bf128) {
+      if (mlp_bf128 && !mlp_pos128) {
         if (nsplit == 3) { if ((rc = launch_mlp_bf_c128<ACT, 3>(mb, xvec, Nmax, st))) return rc; }
         else if (nsplit == 2) { if ((rc = launch_mlp_bf_c128<ACT, 2>(mb, xvec, Nmax, st))) return rc; }
         else if ((rc = launch_mlp_bf_c128<ACT, 1>(mb, xvec, Nmax, st))) return rc;
@@ -2833,7 +2840,8 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
         const int tail_row = px_row > L ? (px_row - L + 15 * max_groups) / 16 : 0;
         const long long tail_units = (long long)B * tail_row;
         const int tub = tail_units > (1 << 24) ? (1 << 24) : (int)tail_units;
-        if ((rc = ftn_launch_mlp_pos64(mp, ACT, nsplit, xvec, tub, st))) return rc;
+        if (mlp_pos128) { if ((rc = ftn_launch_mlp_pos128(mp, ACT, xvec, tub, st))) return rc; }
+        else if ((rc = ftn_launch_mlp_pos64(mp, ACT, nsplit, xvec, tub, st))) return rc;
       } else if (g_mlp_u1 && mb.nsKM == 2 && mb.nsCP == 2 && mb.n_ot == 7) {
         // one 16-pixel unit per wave, four waves per SIMD (see k_mlp_bf_u1)
         if (nsplit == 3) { if ((rc = launch_mlp_bf_u1<ACT, 3, 2, 2, 7>(mb, xvec, Nmax, st))) return rc; }
@@ -2847,9 +2855,6 @@ static int forward_t(const float* x, float* y, int B, int L, const FtnPlan* pl, 
     // D: m' = conv(a')
     ca.in = buf0; ca.bt_L = 0; ca.out = buf1; ca.bias = wb + pl->b_conv2;
     for (int k = 0; k < pl->nbr; ++k) ca.W[k] = wb + pl->w_conv2[k];
-    // stage E on the 16-bit pipe (k_out_h): the second conv then leaves m' as activation pieces
-    const bool out_h = (mlp_bf || mlp_bf128) && ftn_out_h_enabled() != 0 && pl->w_out2fb != 0 && nsplit >= 2 && act_dtype == 0 &&
-                       ((CA <= 64 && CP <= 64) || (CA <= 96 && CP <= 128));
     if (use_bf) {
       cb.in = (const __bf16*)buf0; cb.bt_L = 0; cb.bias = wb + (h2 ? pl->b_conv2s : pl->b_conv2); cb.out_p3 = out_h ? 1 : 0;
       for (int k = 0; k < pl->nbr; ++k) { cb.W[k] = (const __bf16*)(wb + pl->w_convbf2[k]); cb.inv[k] = h2 ? 1.0f / pl->sc_conv2[k] : 1.0f; }

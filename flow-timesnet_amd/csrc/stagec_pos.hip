@@ -424,6 +424,31 @@ static int launch_mlp_pos64(const MlpPosArgs& pa, bool xvec, int tail_units_boun
   return -1;
 }
 
+// d_model-128 shape (three 32-channel branches: K = 96 = three slabs, C = 128 = four slabs, 6 + 8 output tiles; f16x2).
+// 48 registers per group (m pieces 24, a' accumulators 24) + 32 for R: three groups per pass at 256 registers with 42
+// spilled (two fit without spills, but then five groups are three passes: 530 us on the c4 shard against 490 with
+// three and 500 for the pixel-major k_mlp_bf_u1); a chunk's 28 fragments are 84 KB, so ONE 8-wave workgroup per CU
+// (84 KB + 8 x 8 KB of x pieces).  FTN_MLP_POS_GB=2 selects the spill-free form.
+template <int ACT>
+static int launch_mlp_pos128(const MlpPosArgs& pa, bool xvec, int tail_units_bound, hipStream_t st) {
+  const int gb = g_mlp_pos_gb == 2 ? 2 : 3;
+  if (gb == 3)
+    return xvec ? launch_mlp_pos_t<ACT, true, 2, 3, 4, 6, 8, 8, 3, 1, 0>(pa, tail_units_bound, st)
+                : launch_mlp_pos_t<ACT, false, 2, 3, 4, 6, 8, 8, 3, 1, 0>(pa, tail_units_bound, st);
+  return xvec ? launch_mlp_pos_t<ACT, true, 2, 3, 4, 6, 8, 8, 2, 1, 0>(pa, tail_units_bound, st)
+              : launch_mlp_pos_t<ACT, false, 2, 3, 4, 6, 8, 8, 2, 1, 0>(pa, tail_units_bound, st);
+}
+
+int ftn_launch_mlp_pos128(const MlpPosArgs& pa, int act, bool xvec, int tail_units_bound, hipStream_t st) {
+#ifdef FTN_POS_DEV
+  if (act == 0) return launch_mlp_pos128<0>(pa, xvec, tail_units_bound, st);
+  ftn_set_error("FTN_POS_DEV build: only GELU");
+  return -1;
+#else
+  return act == 1 ? launch_mlp_pos128<1>(pa, xvec, tail_units_bound, st) : launch_mlp_pos128<0>(pa, xvec, tail_units_bound, st);
+#endif
+}
+
 int ftn_mlp_pos_enabled() { return g_mlp_pos; }
 
 // FTN_POS_DEV=1 at compile time: only the bench shape's instantiation (GELU, f16x2), for fast kernel iteration
