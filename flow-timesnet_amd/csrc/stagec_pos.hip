@@ -268,14 +268,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void k_mlp_pos(MlpPosArgs pa) {
             ldfrag(NL1 + NOA, f2[0]);
             const float sv[8] = {sacc[0][0], sacc[0][1], sacc[0][2], sacc[0][3], sacc[1][0], sacc[1][1], sacc[1][2], sacc[1][3]};
             split_pieces<NS>(sv, sp);
+            // all NOR accumulator tiles come back from the slab in ONE round trip (the groups' h / hp / fragment
+            // registers are free here), not one per tile
+            f4 rr[NOR];
+#pragma unroll
+            for (int o = 0; o < NOR; ++o) rr[o] = *(const f4*)(rl + o * 1024);
 #pragma unroll
             for (int o = 0; o < NOR; ++o) {
               if (o + 1 < NOR) ldfrag(NL1 + NOA + o + 1, f2[(o + 1) & 1]);
-              f4 r = *(const f4*)(rl + o * 1024);
               __builtin_amdgcn_sched_barrier(0);
-              r = chain_bf<NS>(f2[o & 1], sp, r);
-              *(f4*)(rl + o * 1024) = r;
+              rr[o] = chain_bf<NS>(f2[o & 1], sp, rr[o]);
             }
+#pragma unroll
+            for (int o = 0; o < NOR; ++o) *(f4*)(rl + o * 1024) = rr[o];
           }
         }
       } else
