@@ -26,3 +26,20 @@ def test_parity_slice_under_switch(switch):
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+SLICE_128 = ("test_block_matches_oracle_seeded and 720-128 and f16x2 or "
+             "test_awkward_geometries_match_oracle and 250-128 and f16x2")
+
+
+@pytest.mark.parametrize("switch", ["FTN_MLP_POS=0", "FTN_OUT_H=0", "FTN_CONV_GENERIC=1", "FTN_MLP_POS_GB=2", "FTN_SEL_ROW=0"])
+def test_d_model_128_slice_under_switch(switch):
+    """The d_model-128 forms added late in round 3 - channel-tiled selector, fast conv path for mid 32, position-major
+    stage C (three or two groups per pass), k_out_h with eight output tiles - each against the form it replaced."""
+    name, value = switch.split("=")
+    env = dict(os.environ, **{name: value})
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                        "-k", SLICE_128], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
