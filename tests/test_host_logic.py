@@ -442,3 +442,20 @@ def test_pmc_latest_has_the_layout_bench_reads():
     for prefix in ("k_mlp", "k_conv", "k_spectrum", "k_colsum", "k_finalize("):
         hit = [n for n in names if (n + "(").startswith(prefix)]
         assert hit and all(d["kernels"][n].get("hbm_bytes") is not None for n in hit), prefix
+
+
+def test_every_environment_switch_is_documented():
+    """Each FTN_* / FLOWTIMES_* variable the sources read appears in README.md or DESIGN.md."""
+    import re
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    files = list((root / "flow-timesnet_amd").rglob("*.hip")) + list((root / "flow-timesnet_amd").rglob("*.h")) + \
+        list((root / "flow-timesnet_amd").rglob("*.py")) + [root / "bench.py"]
+    names = set()
+    for f in files:
+        text = f.read_text()
+        names |= set(re.findall(r'getenv\("((?:FTN|FLOWTIMES)_[A-Z0-9_]+)"', text))
+        names |= set(re.findall(r'environ\.get\("((?:FTN|FLOWTIMES)_[A-Z0-9_]+)"', text))
+    docs = (root / "README.md").read_text() + (root / "DESIGN.md").read_text()
+    assert names and not sorted(n for n in names if n not in docs)
